@@ -1,0 +1,419 @@
+// Lowering of a flat SpecializedAst program into kernel launches.  See plan.hpp.
+//
+// The walk below IS the reference's interpreter (src/eval.rs) with every data-touching
+// statement replaced by "emit a launch":
+//   store_in_cache  eval.rs:21-33     add_to_res  eval.rs:35-115
+// Three exact rewrites are applied unless GAAST_FLAG_NO_FUSION is set:
+//   (1) a Product operand that is a bound input holding every wanted grade is read in place
+//       (the kernel applies the `0.0 + x` of the reference's zero-init + add_grades_from copy,
+//       eval.rs:27-31 / graded.rs:74) instead of being copied to a cache buffer;
+//   (2) a Product that is the first writer of a fresh buffer starts its sums from the
+//       zero-initialised accumulator in registers and the zero-fill launch is dropped;
+//   (3) products whose list is a dense slice of the geometric product's table run on the
+//       bitmask-tiled kernel (re-ordered sums: tolerance, not bit-exact; GAAST_FLAG_EXACT_ORDER
+//       keeps them on the exact kernel).
+#include "plan.hpp"
+
+#include <map>
+#include <stdexcept>
+
+namespace gaast {
+namespace {
+
+struct Lowering {
+    const gaast_program_desc& d;
+    Plan& plan;
+    BladeTable bt;
+    std::vector<int> cache;               // node -> node_buffers index, -1 = not cached
+    std::map<std::pair<int, int>, int> fresh;  // buffer -> index of its still-untouched ZERO step
+    std::vector<char> removed;
+
+    Lowering(const gaast_program_desc& desc, Plan& p)
+        : d(desc), plan(p), bt(desc.vec_space_dim), cache(size_t(desc.n_nodes), -1) {}
+
+    const gaast_node_desc& node(int i) const { return d.nodes[i]; }
+
+    const Layout& layout(BufRef r) const {
+        switch (r.kind) {
+        case BufKind::NODE: return plan.node_buffers[size_t(r.idx)];
+        case BufKind::INPUT: return plan.input_layouts[size_t(r.idx)];
+        default: return plan.out_layout;
+        }
+    }
+    static std::pair<int, int> key(BufRef r) { return {int(r.kind), r.idx}; }
+    void touch(BufRef r) { fresh.erase(key(r)); }
+
+    bool fail(int status, const std::string& msg) {
+        if (plan.error == GAAST_OK) {
+            plan.error = status;
+            plan.error_msg = msg;
+        }
+        return false;
+    }
+    bool ok() const { return plan.error == GAAST_OK; }
+
+    Step& emit(Step::Kind k, BufRef res, const std::string& name) {
+        plan.steps.emplace_back();
+        removed.push_back(0);
+        Step& s = plan.steps.back();
+        s.kind = k;
+        s.res = res;
+        s.name = name;
+        return s;
+    }
+
+    void emit_zero(BufRef buf) {
+        emit(Step::ZERO, buf, "zero_fill[init_null_mv]");
+        fresh[key(buf)] = int(plan.steps.size()) - 1;
+    }
+
+    // eval.rs:21-33
+    BufRef store_in_cache(int id) {
+        if (cache[size_t(id)] >= 0) return BufRef{BufKind::NODE, cache[size_t(id)]};
+        plan.node_buffers.push_back(make_layout(node(id).vec_space_dim, node(id).minimal_grade_mask));
+        const int b = int(plan.node_buffers.size()) - 1;
+        cache[size_t(id)] = b;
+        BufRef buf{BufKind::NODE, b};
+        emit_zero(buf);
+        add_to_res(buf, id);
+        return buf;
+    }
+
+    // every offset of the grades of `mask` inside `res`; MISSING_GRADE if res lacks one
+    bool offsets_of(BufRef res, uint64_t mask, std::vector<uint32_t>& out) {
+        const Layout& l = layout(res);
+        for (int k = 0; k < 64; ++k) {
+            if (!((mask >> k) & 1ULL)) continue;
+            if (!((l.mask >> k) & 1ULL))
+                return fail(GAAST_ERR_MISSING_GRADE, "grade " + std::to_string(k) + " absent from result buffer");
+            for (int64_t i = 0; i < l.grade_len(k); ++i) out.push_back(uint32_t(l.offset(k) + i));
+        }
+        return true;
+    }
+
+    void emit_flip(BufRef res, uint64_t mask, const char* what) {
+        std::vector<uint32_t> offs;
+        if (!offsets_of(res, mask, offs)) return;
+        if (offs.empty()) return;
+        Step& s = emit(Step::FLIP, res, std::string("negate_grades[") + what + "]");
+        s.u32_a = std::move(offs);
+        touch(res);
+    }
+
+    // can the operand be read straight from the bound input?
+    bool direct_input_ok(int id) const {
+        const gaast_node_desc& nd = node(id);
+        if (nd.opcode != GAAST_OP_INPUT) return false;
+        const Layout& in = plan.input_layouts[size_t(nd.input_slot)];
+        const uint64_t want = nd.minimal_grade_mask;
+        if ((in.mask & want) != want) return false;  // a wanted grade would stay zero in the copy
+        for (int k = 0; k < 64; ++k)
+            if (((want >> k) & 1ULL) && in.grade_len(k) != int64_t(n_choose_k(uint64_t(nd.vec_space_dim), uint64_t(k))))
+                return false;                         // zip() would truncate (graded.rs:73)
+        return true;
+    }
+
+    // eval.rs:35-115
+    void add_to_res(BufRef res, int id) {
+        if (!ok()) return;
+        const gaast_node_desc& nd = node(id);
+        const uint64_t gs = nd.minimal_grade_mask;
+        if (gs == 0) return;  // eval.rs:40-43
+        switch (nd.opcode) {
+        case GAAST_OP_INPUT: {  // eval.rs:45-50 -> graded.rs:67-78
+            const Layout& in = plan.input_layouts[size_t(nd.input_slot)];
+            const Layout& r = layout(res);
+            std::vector<uint32_t> map;
+            for (int k = 0; k < 64; ++k) {
+                if (!((gs >> k) & 1ULL) || !((in.mask >> k) & 1ULL)) continue;
+                if (!((r.mask >> k) & 1ULL)) {
+                    fail(GAAST_ERR_MISSING_GRADE, "grade " + std::to_string(k) + " absent from result buffer");
+                    return;
+                }
+                const int64_t len = std::min(r.grade_len(k), in.grade_len(k));  // zip
+                for (int64_t i = 0; i < len; ++i)
+                    map.push_back(uint32_t(r.offset(k) + i) | (uint32_t(in.offset(k) + i) << 16));
+            }
+            if (map.empty()) return;
+            Step& s = emit(Step::AXPY, res, "add_grades_from[input " + std::to_string(nd.input_slot) + "]");
+            s.a = BufRef{BufKind::INPUT, nd.input_slot};
+            s.u32_a = std::move(map);
+            touch(res);
+            return;
+        }
+        case GAAST_OP_ADD:  // eval.rs:51-54
+            add_to_res(res, nd.child0);
+            add_to_res(res, nd.child1);
+            return;
+        case GAAST_OP_NEG:  // eval.rs:55-60
+            add_to_res(res, nd.child0);
+            if (ok()) emit_flip(res, gs, "Negation");
+            return;
+        case GAAST_OP_REVERSE: {  // eval.rs:87-94
+            add_to_res(res, nd.child0);
+            if (!ok()) return;
+            if ((gs & 1ULL) && (plan.flags & GAAST_FLAG_DEBUG_OVERFLOW)) {
+                fail(GAAST_ERR_OVERFLOW, "attempt to subtract with overflow (Reverse over grade 0, debug build)");
+                return;
+            }
+            uint64_t m = 0;
+            for (int k = 0; k < 64; ++k)
+                if (((gs >> k) & 1ULL) && (k % 4 == 2 || k % 4 == 3)) m |= 1ULL << k;  // (k(k-1)/2) odd
+            emit_flip(res, m, "Reverse");
+            return;
+        }
+        case GAAST_OP_GINVOL: {  // eval.rs:95-102
+            add_to_res(res, nd.child0);
+            if (!ok()) return;
+            uint64_t m = 0;
+            for (int k = 1; k < 64; k += 2)
+                if ((gs >> k) & 1ULL) m |= 1ULL << k;
+            emit_flip(res, m, "GradeInvolution");
+            return;
+        }
+        case GAAST_OP_SINV:
+        case GAAST_OP_SSQRT: {  // eval.rs:103-110
+            add_to_res(res, nd.child0);
+            if (!ok()) return;
+            const Layout& r = layout(res);
+            if (!(r.mask & 1ULL)) {
+                fail(GAAST_ERR_MISSING_GRADE, "scalar op on a buffer without grade 0");
+                return;
+            }
+            Step& s = emit(Step::SUNARY, res, nd.opcode == GAAST_OP_SINV ? "scalar_inversion" : "scalar_sqrt");
+            s.sunary_op = nd.opcode == GAAST_OP_SINV ? 0 : 1;
+            s.sunary_off = int(r.offset(0));
+            touch(res);
+            return;
+        }
+        case GAAST_OP_PROJ: add_to_res(res, nd.child0); return;  // eval.rs:111
+        case GAAST_OP_EXP:
+        case GAAST_OP_LOG:  // eval.rs:112-113
+            fail(GAAST_ERR_UNIMPLEMENTED, "Exponential / Logarithm evaluation is todo!() in the reference");
+            return;
+        case GAAST_OP_PRODUCT: lower_product(res, id); return;
+        default: throw std::runtime_error("unknown opcode");
+        }
+    }
+
+    BufRef operand(int id, int* canon) {
+        *canon = 0;
+        if (!(plan.flags & GAAST_FLAG_NO_FUSION) && direct_input_ok(id)) {
+            *canon = 1;
+            return BufRef{BufKind::INPUT, node(id).input_slot};
+        }
+        return store_in_cache(id);  // eval.rs:67-68
+    }
+
+    bool dense_eligible(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r) const {
+        if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
+        if (nd.product_kind != GAAST_PROD_GEOMETRIC) return false;
+        const int n = d.vec_space_dim;
+        if (n < 4 || n > 13) return false;
+        if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return false;
+        for (int i = 0; i < n; ++i) {
+            const double g = d.metric_diag[i];
+            if (g != 1.0 && g != -1.0 && g != 0.0) return false;
+            if (i < 4 && g != 1.0) return false;
+        }
+        const double full = double(uint64_t(1) << (2 * n));
+        return double(nd.n_comp_muls) * 16.0 >= full;
+    }
+
+    void lower_product(BufRef res, int id) {  // eval.rs:61-86
+        const gaast_node_desc& nd = node(id);
+        int canon_l = 0, canon_r = 0;
+        BufRef l = operand(nd.child0, &canon_l);
+        if (!ok()) return;
+        BufRef r = operand(nd.child1, &canon_r);
+        if (!ok()) return;
+        if (key(l) == key(res) || key(r) == key(res)) {
+            fail(GAAST_ERR_MISSING_GRADE, "product operand aliases its own result buffer");
+            return;
+        }
+        const Layout &lr = layout(res), &ll = layout(l), &lrr = layout(r);
+        const uint64_t lmin = node(nd.child0).minimal_grade_mask, rmin = node(nd.child1).minimal_grade_mask;
+        const uint64_t omin = nd.minimal_grade_mask;
+        if (nd.comp_muls == nullptr && nd.product_kind < 0)
+            throw std::runtime_error("PRODUCT node has neither a comp-mul list nor a product kind");
+
+        // may the zero-fill of a fresh result buffer be folded into this product?
+        auto fr = fresh.find(key(res));
+        const bool is_fresh = fr != fresh.end() && !(plan.flags & GAAST_FLAG_NO_FUSION);
+
+        if (dense_eligible(nd, res, l, r)) {
+            if ((omin & lr.mask) != omin) {
+                fail(GAAST_ERR_MISSING_GRADE, "product result grade absent from result buffer");
+                return;
+            }
+            const bool beta0 = is_fresh && (lr.mask & ~omin) == 0;
+            if (beta0) {
+                removed[size_t(fr->second)] = 1;
+            }
+            Step& s = emit(Step::PRODUCT_DENSE, res, "product_dense[gp n=" + std::to_string(d.vec_space_dim) + "]");
+            s.a = l;
+            s.b = r;
+            s.canon_a = canon_l;
+            s.canon_b = canon_r;
+            s.beta = beta0 ? 0 : 1;
+            s.n_entries = nd.n_comp_muls;
+            const int n = d.vec_space_dim;
+            auto build_map = [&](const Layout& lay, uint64_t want, std::vector<uint32_t>& map, int* full) {
+                for (int k = 0; k <= n; ++k) {
+                    if (!((want >> k) & 1ULL)) continue;
+                    for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i)
+                        map.push_back(uint32_t(lay.offset(k) + i) | (bt.blade_of[size_t(k)][i] << 16));
+                }
+                *full = map.size() == (size_t(1) << n);
+            };
+            build_map(ll, lmin & ll.mask, s.u32_a, &s.left_full);
+            build_map(lrr, rmin & lrr.mask, s.u32_b, &s.right_full);
+            s.i32_a.assign(size_t(1) << n, -1);
+            for (uint32_t m = 0; m < (1u << n); ++m) {
+                const int g = __builtin_popcount(m);
+                if ((omin >> g) & 1ULL) s.i32_a[m] = int32_t(lr.offset(g) + bt.index_of[m]);
+            }
+            for (int i = 4; i < n; ++i) {
+                if (d.metric_diag[i] == -1.0) s.neg_hi |= 1u << (i - 4);
+                if (d.metric_diag[i] == 0.0) s.zero_hi |= 1u << (i - 4);
+            }
+            s.degenerate = s.zero_hi != 0;
+            touch(res);
+            return;
+        }
+
+        // ---- exact path: CSR by output component, entries in the reference's order ----
+        std::vector<gaast_comp_mul> generated;
+        const gaast_comp_mul* muls = nd.comp_muls;
+        uint64_t n_muls = nd.n_comp_muls;
+        if (!muls) {
+            Selection sel{nd.product_kind, nullptr, nullptr};
+            auto contribs = iter_contribs(omin, sel, lmin, rmin);
+            generated.reserve(size_t(comp_mul_count(d.vec_space_dim, contribs)));
+            for_each_comp_mul(bt, d.metric_diag, contribs,
+                              [&](const gaast_comp_mul& m) { generated.push_back(m); });
+            muls = generated.data();
+            n_muls = generated.size();
+        }
+        if (n_muls == 0) return;  // nothing is added to res
+        if (ll.row_len > 65536 || lrr.row_len > 65536) throw std::runtime_error("operand row too long");
+
+        const bool beta0 = is_fresh;
+        // rows: with beta0 every component of the result row gets a row (empty rows write 0.0)
+        std::vector<int32_t> row_of(size_t(lr.row_len), -1);
+        std::vector<uint32_t> row_out, counts;
+        if (beta0)
+            for (int64_t o = 0; o < lr.row_len; ++o) {
+                row_of[size_t(o)] = int32_t(row_out.size());
+                row_out.push_back(uint32_t(o));
+                counts.push_back(0);
+            }
+        std::vector<uint32_t> eo(static_cast<size_t>(n_muls), 0u);  // output offset of each entry
+        for (uint64_t e = 0; e < n_muls; ++e) {
+            const gaast_comp_mul& m = muls[e];
+            auto check = [&](const Layout& lay, uint32_t g, uint32_t i, const char* what) -> int64_t {
+                if (g >= 64 || !((lay.mask >> g) & 1ULL)) {
+                    fail(GAAST_ERR_MISSING_GRADE, std::string("grade absent from product ") + what);
+                    return -1;
+                }
+                if (int64_t(i) >= lay.grade_len(int(g))) throw std::runtime_error("comp-mul index out of range");
+                return lay.offset(int(g)) + i;
+            };
+            const int64_t lo = check(ll, m.left_grade, m.left_index, "left operand");
+            const int64_t ro = check(lrr, m.right_grade, m.right_index, "right operand");
+            const int64_t oo = check(lr, m.result_grade, m.result_index, "result");
+            if (lo < 0 || ro < 0 || oo < 0) return;
+            if (row_of[size_t(oo)] < 0) {
+                row_of[size_t(oo)] = int32_t(row_out.size());
+                row_out.push_back(uint32_t(oo));
+                counts.push_back(0);
+            }
+            counts[size_t(row_of[size_t(oo)])]++;
+            eo[size_t(e)] = uint32_t(oo);
+        }
+        if (beta0) removed[size_t(fr->second)] = 1;
+        Step& s = emit(Step::PRODUCT_CSR, res, "product_csr[" + std::to_string(n_muls) + " comp-muls]");
+        s.a = l;
+        s.b = r;
+        s.canon_a = canon_l;
+        s.canon_b = canon_r;
+        s.beta = beta0 ? 0 : 1;
+        s.n_entries = n_muls;
+        s.u32_a.assign(row_out.size() + 1, 0);
+        for (size_t i = 0; i < counts.size(); ++i) s.u32_a[i + 1] = s.u32_a[i] + counts[i];
+        s.u32_b = row_out;
+        s.u32_c.resize(size_t(n_muls));
+        s.coeff.resize(size_t(n_muls));
+        std::vector<uint32_t> cursor(s.u32_a.begin(), s.u32_a.end() - 1);
+        for (uint64_t e = 0; e < n_muls; ++e) {  // stable: keeps the reference order per output
+            const gaast_comp_mul& m = muls[e];
+            const uint32_t pos = cursor[size_t(row_of[eo[size_t(e)]])]++;
+            const uint32_t lo = uint32_t(ll.offset(int(m.left_grade)) + m.left_index);
+            const uint32_t ro = uint32_t(lrr.offset(int(m.right_grade)) + m.right_index);
+            s.u32_c[pos] = lo | (ro << 16);
+            s.coeff[pos] = m.coeff;
+        }
+        touch(res);
+    }
+};
+
+}  // namespace
+
+void build_plan(const gaast_program_desc& desc, Plan& plan) {
+    if (desc.vec_space_dim < 0 || desc.vec_space_dim > GAAST_MAX_DIM) throw std::runtime_error("vec_space_dim out of range");
+    if (desc.n_nodes <= 0 || desc.root < 0 || desc.root >= desc.n_nodes) throw std::runtime_error("bad node count / root");
+    if (desc.dtype != GAAST_F64 && desc.dtype != GAAST_F32) throw std::runtime_error("bad dtype");
+    if (desc.n_inputs < 0 || desc.n_inputs > GAAST_MAX_INPUTS) throw std::runtime_error("too many inputs");
+    plan.n = desc.vec_space_dim;
+    plan.dtype = desc.dtype;
+    plan.flags = desc.flags;
+    plan.metric.assign(desc.metric_diag, desc.metric_diag + desc.vec_space_dim);
+    plan.inputs.assign(desc.inputs, desc.inputs + desc.n_inputs);
+    plan.const_rows.resize(size_t(desc.n_inputs));
+    plan.input_layouts.resize(size_t(desc.n_inputs));
+    for (int i = 0; i < desc.n_inputs; ++i) {
+        const gaast_input_desc& in = desc.inputs[i];
+        if (in.storage_dim < 0 || in.storage_dim > GAAST_MAX_DIM) throw std::runtime_error("input storage_dim out of range");
+        plan.input_layouts[size_t(i)] = make_layout(in.storage_dim, in.grade_mask);
+        if (in.is_const) {
+            const int64_t len = plan.input_layouts[size_t(i)].row_len;
+            if (len && !in.const_row) throw std::runtime_error("constant input without data");
+            plan.const_rows[size_t(i)].assign(in.const_row, in.const_row + len);
+            plan.inputs[size_t(i)].const_row = nullptr;  // no host pointer is retained
+        }
+    }
+    for (int i = 0; i < desc.n_nodes; ++i) {
+        const gaast_node_desc& nd = desc.nodes[i];
+        auto child_ok = [&](int c) { return c >= 0 && c < i; };
+        switch (nd.opcode) {
+        case GAAST_OP_INPUT:
+            if (nd.input_slot < 0 || nd.input_slot >= desc.n_inputs) throw std::runtime_error("input slot out of range");
+            break;
+        case GAAST_OP_ADD:
+        case GAAST_OP_PRODUCT:
+            if (!child_ok(nd.child0) || !child_ok(nd.child1)) throw std::runtime_error("nodes are not in post-order");
+            break;
+        case GAAST_OP_NEG: case GAAST_OP_EXP: case GAAST_OP_LOG: case GAAST_OP_PROJ:
+        case GAAST_OP_REVERSE: case GAAST_OP_GINVOL: case GAAST_OP_SINV: case GAAST_OP_SSQRT:
+            if (!child_ok(nd.child0)) throw std::runtime_error("nodes are not in post-order");
+            break;
+        default: throw std::runtime_error("unknown opcode");
+        }
+        if (nd.vec_space_dim < 0 || nd.vec_space_dim > GAAST_MAX_DIM) throw std::runtime_error("node dim out of range");
+    }
+
+    Lowering lw(desc, plan);
+    // eval.rs:12-19: the root is cached like any other node; its buffer is the caller's `out`
+    const gaast_node_desc& root = desc.nodes[desc.root];
+    plan.out_layout = make_layout(root.vec_space_dim, root.minimal_grade_mask);
+    BufRef out{BufKind::OUT, 0};
+    lw.emit_zero(out);
+    lw.add_to_res(out, desc.root);
+    // drop the zero-fills that were folded into products
+    std::vector<Step> kept;
+    for (size_t i = 0; i < plan.steps.size(); ++i)
+        if (!lw.removed[i]) kept.push_back(std::move(plan.steps[i]));
+    plan.steps = std::move(kept);
+}
+
+}  // namespace gaast

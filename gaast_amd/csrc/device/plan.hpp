@@ -1,0 +1,80 @@
+// Lowering of a flat SpecializedAst program into a launch plan that reproduces the control
+// flow of the reference's interpreter (src/eval.rs:12-115) arm by arm.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../common/algebra.hpp"
+#include "../common/comp_mul_table.hpp"
+#include "gaast_hip.h"
+
+namespace gaast {
+
+enum class BufKind : int { NODE = 0, INPUT = 1, OUT = 2 };
+
+struct BufRef {
+    BufKind kind = BufKind::NODE;
+    int idx = -1;  // NODE: cache-buffer id; INPUT: slot
+};
+
+struct Layout {  // how a graded row is laid out
+    int dim = 0;
+    uint64_t mask = 0;
+    int64_t row_len = 0;
+    int64_t offset(int k) const { return grade_offset(dim, mask, k); }
+    int64_t grade_len(int k) const { return int64_t(n_choose_k(uint64_t(dim), uint64_t(k))); }
+};
+
+inline Layout make_layout(int dim, uint64_t mask) {
+    Layout l;
+    l.dim = dim;
+    l.mask = mask;
+    l.row_len = row_len_of(dim, mask);
+    return l;
+}
+
+struct Step {
+    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE } kind = ZERO;
+    BufRef res, a, b;
+    std::string name;
+    // host images of the tables (uploaded once at program_create)
+    std::vector<uint32_t> u32_a;   // AXPY map | FLIP offsets | CSR row_start | DENSE left_map
+    std::vector<uint32_t> u32_b;   // CSR row_out | DENSE right_map
+    std::vector<uint32_t> u32_c;   // CSR entries
+    std::vector<double> coeff;     // CSR coefficients (converted to the program dtype on upload)
+    std::vector<int32_t> i32_a;    // DENSE out_map
+    int sunary_op = 0, sunary_off = 0;
+    int canon_a = 0, canon_b = 0;
+    int beta = 1;
+    int left_full = 0, right_full = 0;
+    uint32_t neg_hi = 0, zero_hi = 0;
+    int degenerate = 0;
+    uint64_t n_entries = 0;  // comp-mul count this step stands for
+    // device copies
+    void* d_a = nullptr;
+    void* d_b = nullptr;
+    void* d_c = nullptr;
+    void* d_coeff = nullptr;
+    void* d_i32 = nullptr;
+};
+
+struct Plan {
+    int n = 0;
+    int dtype = GAAST_F64;
+    uint32_t flags = 0;
+    std::vector<double> metric;
+    std::vector<gaast_input_desc> inputs;
+    std::vector<std::vector<double>> const_rows;
+    std::vector<Layout> input_layouts;
+    std::vector<Layout> node_buffers;  // cache buffers other than the root's
+    Layout out_layout;
+    std::vector<Step> steps;
+    int error = GAAST_OK;              // what the reference would have panicked with, at eval
+    std::string error_msg;
+};
+
+// Throws std::runtime_error (-> GAAST_ERR_INVALID_PROGRAM) on malformed input.
+void build_plan(const gaast_program_desc& desc, Plan& plan);
+
+}  // namespace gaast

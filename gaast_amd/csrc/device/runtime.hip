@@ -1,0 +1,520 @@
+// C ABI of the gfx950 back end (include/gaast_hip.h): device storage of graded rows, program
+// objects (launch plans) and the batched evaluator.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gaast_hip.h"
+#include "kernels.hip.hpp"
+#include "plan.hpp"
+
+using namespace gaast;
+
+// ------------------------------------------------------------------------------------------
+// state
+// ------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+bool g_init = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+int g_num_cu = 256;
+size_t g_max_lds = 160 * 1024;
+
+int set_err(int status, const std::string& msg) {
+    g_err = msg;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return set_err(GAAST_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+int ensure_init() {
+    if (g_init) return GAAST_OK;
+    return set_err(GAAST_ERR_NO_DEVICE, "gaast_hip_init() has not been called (or found no GPU)");
+}
+
+size_t dtype_size(int dtype) { return dtype == GAAST_F32 ? 4 : 8; }
+
+}  // namespace
+
+struct gaast_hip_mv_s {
+    Layout layout;
+    int64_t batch = 0;
+    int dtype = GAAST_F64;
+    int64_t row_stride = 0;  // elements
+    void* ptr = nullptr;
+    bool owns = false;
+};
+
+struct gaast_hip_program_s {
+    Plan plan;
+    std::vector<gaast_hip_mv_t> const_mvs;  // per input slot (nullptr for bound slots)
+    std::vector<gaast_hip_mv_t> scratch;    // per node buffer, sized for scratch_batch
+    int64_t scratch_batch = 0;
+    std::vector<std::string> launch_names;
+};
+
+namespace {
+
+template <typename T>
+int upload_vec(const std::vector<T>& v, void** dptr) {
+    *dptr = nullptr;
+    if (v.empty()) return GAAST_OK;
+    HIP_TRY(hipMalloc(dptr, v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GAAST_OK;
+}
+
+int mv_alloc_impl(int dim, uint64_t mask, int64_t batch, int dtype, gaast_hip_mv_t* out) {
+    auto* m = new gaast_hip_mv_s;
+    m->layout = make_layout(dim, mask);
+    m->batch = batch;
+    m->dtype = dtype;
+    m->row_stride = m->layout.row_len;
+    m->owns = true;
+    const size_t bytes = size_t(batch) * size_t(m->layout.row_len) * dtype_size(dtype);
+    if (bytes) {
+        hipError_t e = hipMalloc(&m->ptr, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(m->ptr, 0, bytes, g_stream);
+        if (e != hipSuccess) {
+            if (m->ptr) (void)hipFree(m->ptr);
+            delete m;
+            return set_err(GAAST_ERR_HIP, std::string("mv_alloc: ") + hipGetErrorString(e));
+        }
+    }
+    *out = m;
+    return GAAST_OK;
+}
+
+void mv_free_impl(gaast_hip_mv_t m) {
+    if (!m) return;
+    if (m->owns && m->ptr) (void)hipFree(m->ptr);
+    delete m;
+}
+
+int grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = int64_t(g_num_cu) * 8;  // grid-stride beyond 8 blocks per CU
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return int(g);
+}
+
+struct Bound {  // a buffer resolved for one eval call
+    void* ptr;
+    int64_t stride;
+};
+
+template <typename T>
+int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, const Layout& la,
+             const Layout& lb, int64_t batch, int n) {
+    switch (s.kind) {
+    case Step::ZERO: return GAAST_OK;  // handled by the caller (needs the row length)
+    case Step::AXPY: {
+        const int nm = int(s.u32_a.size());
+        hipLaunchKernelGGL(k_axpy_map<T>, dim3(grid_for(batch * nm, 256)), dim3(256), 0, g_stream,
+                           static_cast<T*>(res.ptr), res.stride, static_cast<const T*>(a.ptr), a.stride,
+                           static_cast<const uint32_t*>(s.d_a), nm, batch);
+        break;
+    }
+    case Step::FLIP: {
+        const int nm = int(s.u32_a.size());
+        hipLaunchKernelGGL(k_flip<T>, dim3(grid_for(batch * nm, 256)), dim3(256), 0, g_stream,
+                           static_cast<T*>(res.ptr), res.stride, static_cast<const uint32_t*>(s.d_a), nm, batch);
+        break;
+    }
+    case Step::SUNARY:
+        hipLaunchKernelGGL(k_scalar_unary<T>, dim3(grid_for(batch, 256)), dim3(256), 0, g_stream,
+                           static_cast<T*>(res.ptr), res.stride, s.sunary_off, s.sunary_op, batch);
+        break;
+    case Step::PRODUCT_CSR: {
+        CsrArgs<T> p;
+        p.left = static_cast<const T*>(a.ptr);
+        p.right = static_cast<const T*>(b.ptr);
+        p.out = static_cast<T*>(res.ptr);
+        p.left_stride = a.stride;
+        p.right_stride = b.stride;
+        p.out_stride = res.stride;
+        p.left_len = int(la.row_len);
+        p.right_len = int(lb.row_len);
+        p.canon_left = s.canon_a;
+        p.canon_right = s.canon_b;
+        p.row_start = static_cast<const uint32_t*>(s.d_a);
+        p.row_out = static_cast<const uint32_t*>(s.d_b);
+        p.entries = static_cast<const uint32_t*>(s.d_c);
+        p.coeff = static_cast<const T*>(s.d_coeff);
+        p.n_rows = int(s.u32_b.size());
+        p.beta = s.beta;
+        p.batch = batch;
+        const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
+        if (per_item > g_max_lds)
+            return set_err(GAAST_ERR_INVALID_PROGRAM, "product operands do not fit in LDS (exact kernel)");
+        // enough items per block to give 256 threads work, within a 64 KiB LDS budget
+        int items = int((256 + p.n_rows - 1) / (p.n_rows > 0 ? p.n_rows : 1));
+        const size_t budget = 64 * 1024;
+        if (per_item * size_t(items) > budget) items = int(budget / per_item);
+        if (items < 1) items = 1;
+        if (int64_t(items) > batch) items = int(batch);
+        p.items = items;
+        const size_t lds = per_item * size_t(items);
+        const int64_t blocks = (batch + items - 1) / items;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_csr<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(k_product_csr<T>, dim3(unsigned(blocks)), dim3(256), lds, g_stream, p);
+        break;
+    }
+    case Step::PRODUCT_DENSE: {
+        DenseArgs<T> p;
+        p.left = static_cast<const T*>(a.ptr);
+        p.right = static_cast<const T*>(b.ptr);
+        p.out = static_cast<T*>(res.ptr);
+        p.left_stride = a.stride;
+        p.right_stride = b.stride;
+        p.out_stride = res.stride;
+        p.left_map = static_cast<const uint32_t*>(s.d_a);
+        p.right_map = static_cast<const uint32_t*>(s.d_b);
+        p.left_count = int(s.u32_a.size());
+        p.right_count = int(s.u32_b.size());
+        p.left_full = s.left_full;
+        p.right_full = s.right_full;
+        p.out_map = static_cast<const int32_t*>(s.d_i32);
+        p.canon_left = s.canon_a;
+        p.canon_right = s.canon_b;
+        p.n = n;
+        p.neg_hi = s.neg_hi;
+        p.zero_hi = s.zero_hi;
+        p.beta = s.beta;
+        p.batch = batch;
+        const int lpi = 1 << (n - 4);
+        const int threads = lpi > 256 ? lpi : 256;
+        const int ipb = threads / lpi;
+        const size_t lds = size_t(ipb) * size_t(2 * (1 << n) + 4) * sizeof(T);
+        if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
+        const int64_t blocks = (batch + ipb - 1) / ipb;
+        auto kern = s.degenerate ? &k_gp_dense<T, true> : &k_gp_dense<T, false>;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
+        break;
+    }
+    }
+    HIP_TRY(hipGetLastError());
+    return GAAST_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gaast_hip_last_error(void) { return g_err.c_str(); }
+const char* gaast_hip_version(void) { return "gaast-hip 0.1 (gfx950)"; }
+
+int gaast_hip_init(const int* device_ids, int n_dev) {
+    if (n_dev != 1 || !device_ids)
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "one process drives one GPU: pass exactly one device id");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return set_err(GAAST_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_ids[0] < 0 || device_ids[0] >= count) return set_err(GAAST_ERR_INVALID_ARGUMENT, "device id out of range");
+    HIP_TRY(hipSetDevice(device_ids[0]));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ids[0]));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(GAAST_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, found ") + prop.gcnArchName);
+    g_num_cu = prop.multiProcessorCount;
+    g_max_lds = prop.maxSharedMemoryPerMultiProcessor ? size_t(prop.maxSharedMemoryPerMultiProcessor) : size_t(160 * 1024);
+    if (g_max_lds > 160 * 1024) g_max_lds = 160 * 1024;
+    g_device = device_ids[0];
+    g_stream = nullptr;
+    g_init = true;
+    return GAAST_OK;
+}
+
+int gaast_hip_shutdown(void) {
+    g_init = false;
+    return GAAST_OK;
+}
+
+int gaast_hip_set_stream(void* hip_stream) {
+    g_stream = static_cast<hipStream_t>(hip_stream);
+    return GAAST_OK;
+}
+
+int gaast_hip_synchronize(void) {
+    if (int st = ensure_init()) return st;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return GAAST_OK;
+}
+
+int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t* out) {
+    if (!desc || !out) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    auto prog = std::make_unique<gaast_hip_program_s>();
+    try {
+        build_plan(*desc, prog->plan);
+    } catch (const std::exception& ex) {
+        return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
+    }
+    Plan& plan = prog->plan;
+    for (Step& s : plan.steps) {
+        if (int st = upload_vec(s.u32_a, &s.d_a)) return st;
+        if (int st = upload_vec(s.u32_b, &s.d_b)) return st;
+        if (int st = upload_vec(s.u32_c, &s.d_c)) return st;
+        if (int st = upload_vec(s.i32_a, &s.d_i32)) return st;
+        if (!s.coeff.empty()) {
+            if (plan.dtype == GAAST_F32) {
+                std::vector<float> cf(s.coeff.begin(), s.coeff.end());
+                if (int st = upload_vec(cf, &s.d_coeff)) return st;
+            } else {
+                if (int st = upload_vec(s.coeff, &s.d_coeff)) return st;
+            }
+        }
+        // the host images of the big tables are no longer needed
+        std::vector<uint32_t>().swap(s.u32_c);
+        std::vector<double>().swap(s.coeff);
+        prog->launch_names.push_back(s.name);
+    }
+    prog->const_mvs.assign(plan.inputs.size(), nullptr);
+    for (size_t i = 0; i < plan.inputs.size(); ++i) {
+        if (!plan.inputs[i].is_const) continue;
+        const Layout& l = plan.input_layouts[i];
+        gaast_hip_mv_t m = nullptr;
+        if (int st = mv_alloc_impl(l.dim, l.mask, 1, plan.dtype, &m)) return st;
+        prog->const_mvs[i] = m;
+        if (l.row_len) {
+            if (plan.dtype == GAAST_F32) {
+                std::vector<float> r(plan.const_rows[i].begin(), plan.const_rows[i].end());
+                HIP_TRY(hipMemcpy(m->ptr, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(hipMemcpy(m->ptr, plan.const_rows[i].data(), plan.const_rows[i].size() * 8,
+                                  hipMemcpyHostToDevice));
+            }
+        }
+    }
+    *out = prog.release();
+    return GAAST_OK;
+}
+
+int gaast_hip_program_destroy(gaast_hip_program_t prog) {
+    if (!prog) return GAAST_OK;
+    for (Step& s : prog->plan.steps)
+        for (void* p : {s.d_a, s.d_b, s.d_c, s.d_coeff, s.d_i32})
+            if (p) (void)hipFree(p);
+    for (gaast_hip_mv_t m : prog->const_mvs) mv_free_impl(m);
+    for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
+    delete prog;
+    return GAAST_OK;
+}
+
+int gaast_hip_program_output_info(gaast_hip_program_t prog, uint64_t* grade_mask, int64_t* row_len) {
+    if (!prog) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null program");
+    if (grade_mask) *grade_mask = prog->plan.out_layout.mask;
+    if (row_len) *row_len = prog->plan.out_layout.row_len;
+    return GAAST_OK;
+}
+
+int gaast_hip_program_num_launches(gaast_hip_program_t prog) { return prog ? int(prog->launch_names.size()) : 0; }
+const char* gaast_hip_program_launch_name(gaast_hip_program_t prog, int i) {
+    if (!prog || i < 0 || i >= int(prog->launch_names.size())) return "";
+    return prog->launch_names[size_t(i)].c_str();
+}
+
+int gaast_hip_mv_alloc(int dim, uint64_t grade_mask, int64_t batch, int dtype, gaast_hip_mv_t* out) {
+    if (!out || dim < 0 || dim > GAAST_MAX_DIM || batch < 0 || (dtype != GAAST_F64 && dtype != GAAST_F32))
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad mv_alloc argument");
+    if (int st = ensure_init()) return st;
+    return mv_alloc_impl(dim, grade_mask, batch, dtype, out);
+}
+
+int gaast_hip_mv_wrap(void* device_ptr, int dim, uint64_t grade_mask, int64_t batch, int dtype,
+                      int64_t row_stride, gaast_hip_mv_t* out) {
+    if (!out || dim < 0 || dim > GAAST_MAX_DIM || batch < 0 || (dtype != GAAST_F64 && dtype != GAAST_F32))
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad mv_wrap argument");
+    auto* m = new gaast_hip_mv_s;
+    m->layout = make_layout(dim, grade_mask);
+    if (row_stride < m->layout.row_len && !(batch <= 1)) {
+        delete m;
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "row_stride shorter than the row");
+    }
+    m->batch = batch;
+    m->dtype = dtype;
+    m->row_stride = row_stride;
+    m->ptr = device_ptr;
+    m->owns = false;
+    *out = m;
+    return GAAST_OK;
+}
+
+int gaast_hip_mv_free(gaast_hip_mv_t mv) {
+    mv_free_impl(mv);
+    return GAAST_OK;
+}
+
+int gaast_hip_mv_info(gaast_hip_mv_t mv, int* dim, uint64_t* grade_mask, int64_t* batch, int* dtype,
+                      int64_t* row_len, int64_t* row_stride, void** device_ptr) {
+    if (!mv) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null mv");
+    if (dim) *dim = mv->layout.dim;
+    if (grade_mask) *grade_mask = mv->layout.mask;
+    if (batch) *batch = mv->batch;
+    if (dtype) *dtype = mv->dtype;
+    if (row_len) *row_len = mv->layout.row_len;
+    if (row_stride) *row_stride = mv->row_stride;
+    if (device_ptr) *device_ptr = mv->ptr;
+    return GAAST_OK;
+}
+
+static int mv_copy_grade(gaast_hip_mv_t mv, int grade, void* host, int64_t count, bool upload) {
+    if (!mv || !host) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    if (grade < 0 || grade > 63 || !((mv->layout.mask >> grade) & 1ULL))
+        return set_err(GAAST_ERR_MISSING_GRADE, "grade " + std::to_string(grade) + " absent from this multivector");
+    const int64_t glen = mv->layout.grade_len(grade);
+    if (count != glen * mv->batch) return set_err(GAAST_ERR_INVALID_ARGUMENT, "count must be C(dim,k) * batch");
+    if (count == 0) return GAAST_OK;
+    const size_t sz = dtype_size(mv->dtype);
+    char* dev = static_cast<char*>(mv->ptr) + size_t(mv->layout.offset(grade)) * sz;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (upload)
+        HIP_TRY(hipMemcpy2D(dev, size_t(mv->row_stride) * sz, host, size_t(glen) * sz, size_t(glen) * sz,
+                            size_t(mv->batch), hipMemcpyHostToDevice));
+    else
+        HIP_TRY(hipMemcpy2D(host, size_t(glen) * sz, dev, size_t(mv->row_stride) * sz, size_t(glen) * sz,
+                            size_t(mv->batch), hipMemcpyDeviceToHost));
+    return GAAST_OK;
+}
+
+int gaast_hip_mv_upload(gaast_hip_mv_t mv, int grade, const void* host, int64_t count) {
+    return mv_copy_grade(mv, grade, const_cast<void*>(host), count, true);
+}
+int gaast_hip_mv_download(gaast_hip_mv_t mv, int grade, void* host, int64_t count) {
+    return mv_copy_grade(mv, grade, host, count, false);
+}
+
+static int mv_copy_rows(gaast_hip_mv_t mv, void* host, int64_t count, bool upload) {
+    if (!mv || (!host && count)) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    const int64_t rl = mv->layout.row_len;
+    if (count != rl * mv->batch) return set_err(GAAST_ERR_INVALID_ARGUMENT, "count must be row_len * batch");
+    if (count == 0) return GAAST_OK;
+    const size_t sz = dtype_size(mv->dtype);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (upload)
+        HIP_TRY(hipMemcpy2D(mv->ptr, size_t(mv->row_stride) * sz, host, size_t(rl) * sz, size_t(rl) * sz,
+                            size_t(mv->batch), hipMemcpyHostToDevice));
+    else
+        HIP_TRY(hipMemcpy2D(host, size_t(rl) * sz, mv->ptr, size_t(mv->row_stride) * sz, size_t(rl) * sz,
+                            size_t(mv->batch), hipMemcpyDeviceToHost));
+    return GAAST_OK;
+}
+
+int gaast_hip_mv_upload_rows(gaast_hip_mv_t mv, const void* host, int64_t count) {
+    return mv_copy_rows(mv, const_cast<void*>(host), count, true);
+}
+int gaast_hip_mv_download_rows(gaast_hip_mv_t mv, void* host, int64_t count) {
+    return mv_copy_rows(mv, host, count, false);
+}
+
+int gaast_hip_mv_zero(gaast_hip_mv_t mv) {
+    if (!mv) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null mv");
+    if (int st = ensure_init()) return st;
+    const size_t sz = dtype_size(mv->dtype);
+    if (mv->batch && mv->layout.row_len)
+        HIP_TRY(hipMemset2DAsync(mv->ptr, size_t(mv->row_stride) * sz, 0, size_t(mv->layout.row_len) * sz,
+                                 size_t(mv->batch), g_stream));
+    return GAAST_OK;
+}
+
+int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inputs, int64_t batch,
+                   gaast_hip_mv_t out) {
+    if (!prog || !out || batch < 0) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    Plan& plan = prog->plan;
+    if (plan.error != GAAST_OK) return set_err(plan.error, plan.error_msg);  // the reference panics here
+    if (n_inputs < 0 || (n_inputs && !inputs)) return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad inputs");
+
+    // bind inputs (GradedObj values)
+    std::vector<Bound> in_bound(plan.inputs.size(), Bound{nullptr, 0});
+    for (size_t i = 0; i < plan.inputs.size(); ++i) {
+        gaast_hip_mv_t m = plan.inputs[i].is_const ? prog->const_mvs[i] : (int(i) < n_inputs ? inputs[i] : nullptr);
+        const Layout& want = plan.input_layouts[i];
+        if (!m) {
+            // slots no node refers to may stay unbound
+            bool used = false;
+            for (const Step& s : plan.steps)
+                used |= (s.a.kind == BufKind::INPUT && s.a.idx == int(i)) || (s.b.kind == BufKind::INPUT && s.b.idx == int(i));
+            if (used) return set_err(GAAST_ERR_INVALID_ARGUMENT, "input slot " + std::to_string(i) + " is not bound");
+            continue;
+        }
+        if (m->layout.mask != want.mask || m->layout.dim != want.dim)
+            return set_err(GAAST_ERR_INVALID_ARGUMENT, "input slot " + std::to_string(i) + ": grade set / dimension differ from the program's");
+        if (m->dtype != plan.dtype) return set_err(GAAST_ERR_INVALID_ARGUMENT, "input dtype differs from the program's");
+        if (m->batch != batch && m->batch != 1)
+            return set_err(GAAST_ERR_INVALID_ARGUMENT, "input batch must equal the eval batch or be 1 (shared)");
+        in_bound[i] = Bound{m->ptr, (m->batch == 1 && batch != 1) ? 0 : m->row_stride};
+    }
+    if (out->layout.mask != plan.out_layout.mask || out->layout.dim != plan.out_layout.dim)
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "output grade set / dimension differ from the root's");
+    if (out->dtype != plan.dtype || out->batch != batch)
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "output dtype / batch mismatch");
+    if (batch == 0) return GAAST_OK;
+
+    // cache buffers of the product operands (the per-eval HashMap<NodeId, R> of eval.rs:16)
+    if (prog->scratch_batch < batch || prog->scratch.size() != plan.node_buffers.size()) {
+        for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
+        prog->scratch.clear();
+        for (const Layout& l : plan.node_buffers) {
+            gaast_hip_mv_t m = nullptr;
+            if (int st = mv_alloc_impl(l.dim, l.mask, batch, plan.dtype, &m)) return st;
+            prog->scratch.push_back(m);
+        }
+        prog->scratch_batch = batch;
+    }
+
+    const size_t sz = dtype_size(plan.dtype);
+    auto resolve = [&](BufRef r, Layout* lay) -> Bound {
+        switch (r.kind) {
+        case BufKind::NODE: {
+            gaast_hip_mv_t m = prog->scratch[size_t(r.idx)];
+            *lay = m->layout;
+            return Bound{m->ptr, m->row_stride};
+        }
+        case BufKind::INPUT: *lay = plan.input_layouts[size_t(r.idx)]; return in_bound[size_t(r.idx)];
+        default: *lay = out->layout; return Bound{out->ptr, out->row_stride};
+        }
+    };
+    for (const Step& s : plan.steps) {
+        Layout lres, la, lb;
+        const Bound res = resolve(s.res, &lres);
+        if (s.kind == Step::ZERO) {
+            if (lres.row_len)
+                HIP_TRY(hipMemset2DAsync(res.ptr, size_t(res.stride) * sz, 0, size_t(lres.row_len) * sz,
+                                         size_t(batch), g_stream));
+            continue;
+        }
+        Bound a{nullptr, 0}, b{nullptr, 0};
+        if (s.a.idx >= 0) a = resolve(s.a, &la);
+        if (s.b.idx >= 0) b = resolve(s.b, &lb);
+        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, batch, plan.n)
+                                               : run_step<double>(s, res, a, b, la, lb, batch, plan.n);
+        if (st != GAAST_OK) return st;
+    }
+    return GAAST_OK;
+}
+
+}  // extern "C"

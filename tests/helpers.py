@@ -1,0 +1,132 @@
+"""Shared test plumbing: one expression source, two back ends.
+
+`ORACLE` wraps oracle/pyoracle.py (the CPU restatement of the reference: the checker) and
+`HIP` wraps gaast_amd (the product).  An expression is written once as a function of a
+back end `B` using the reference's operator surface, e.g.
+
+    lambda B: (B.value(a) + B.value(b) * B.value(c)).g(2)
+
+and then specialised / evaluated by both.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import gaast_amd as ga
+from oracle import pyoracle as og
+
+
+def n_choose_k(n, k):
+    return og.lib().og_n_choose_k(n, k)
+
+
+def full_grades(n):
+    return list(range(n + 1))
+
+
+def random_mv(rng, n, grades, lo=-1.0, hi=1.0):
+    """dict grade -> f64 array of C(n,k) uniform values"""
+    return {k: rng.uniform(lo, hi, n_choose_k(n, k)) for k in grades}
+
+
+def rows_of(n, grades, batch, rng, dtype=np.float64):
+    """[batch, row_len] item-major rows for the given grades"""
+    rl = sum(n_choose_k(n, k) for k in sorted(grades))
+    return rng.uniform(-1.0, 1.0, (batch, rl)).astype(dtype)
+
+
+def split_row(n, grades, row):
+    out, pos = {}, 0
+    for k in sorted(grades):
+        g = n_choose_k(n, k)
+        out[k] = np.asarray(row[pos:pos + g], dtype=np.float64)
+        pos += g
+    return out
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.inputs = {}  # slot -> (GradeMapMV, grades, dim)
+
+    def basis_vectors(self, n):
+        return og.Expr.basis_vectors(n)
+
+    def value(self, grades, dim=None):
+        return og.mv(og.GradeMapMV({k: np.asarray(v, dtype=np.float64) for k, v in grades.items()}))
+
+    def scalar(self, x):
+        return og.Expr._lift(float(x))
+
+    def input(self, slot, grades, dim):
+        """per-item input: bound to a mutable GradeMapMV that eval_batch rewrites"""
+        if slot not in self.inputs:
+            m = og.GradeMapMV({k: np.zeros(n_choose_k(dim, k)) for k in grades})
+            self.inputs[slot] = (m, sorted(grades), dim)
+        return og.mv(self.inputs[slot][0])
+
+
+class HipBackend:
+    name = "hip"
+
+    def basis_vectors(self, n):
+        return ga.Expr.basis_vectors(n)
+
+    def value(self, grades, dim=None):
+        return ga.mv(ga.GradeMapMV(grades, dim=dim))
+
+    def scalar(self, x):
+        return ga.Expr._lift(float(x))
+
+    def input(self, slot, grades, dim):
+        return ga.mv(ga.Input(slot, grades, dim))
+
+
+def oracle_eval_batch(build, alg, input_rows, batch, mode=og.EVAL_RELEASE):
+    """Run the oracle once per item.  input_rows: {slot: [batch,row] or [1,row] (shared)}.
+    Returns (rows [batch, out_len] f64, out_mask)."""
+    B = OracleBackend()
+    spec = build(B).specialize(alg)
+    root = spec.nodes()[spec.root()]
+    dim = root.vec_space_dim
+    out_len = sum(n_choose_k(dim, k) for k in range(64) if (root.minimal >> k) & 1)
+    slots = sorted(B.inputs)
+    mvs = [B.inputs[s][0] for s in slots]
+    data = []
+    for s in slots:
+        rows = np.asarray(input_rows[s], dtype=np.float64)
+        if rows.shape[0] == 1 and batch > 1:
+            rows = np.repeat(rows, batch, axis=0)
+        data.append(rows)
+    out = spec.eval_batch(mvs, data, batch, out_len, mode)
+    return out, root.minimal
+
+
+def hip_eval_batch(build, alg, input_rows, batch, dtype=ga.F64, flags=0, **kw):
+    """Same through the C ABI on the GPU.  Returns (rows [batch,out_len], out_mask, spec)."""
+    spec = build(HipBackend()).specialize(alg, dtype=dtype, flags=flags, **kw)
+    n_slots = spec.num_user_inputs()
+    ins = [input_rows.get(s) for s in range(n_slots)]
+    out = spec.eval_batch(ins, batch)
+    ga.lib().gaast_hip_synchronize()
+    return out.download_rows(), out.mask, spec
+
+
+def assert_same_ast(ospec, hspec):
+    """Phases 1-3 of the product agree with the oracle node for node, entry for entry."""
+    onodes, hnodes = ospec.nodes(), hspec.nodes()
+    assert len(onodes) == len(hnodes)
+    assert ospec.root() == hspec.root_id()
+    for i, (o, h) in enumerate(zip(onodes, hnodes)):
+        assert o.kind == h.opcode, f"node {i}: kind {og.NODE_KINDS[o.kind]} vs {h.opcode}"
+        assert (o.child0, o.child1) == (h.child0, h.child1), f"node {i}: children"
+        assert o.maximal == h.maximal_grade_mask, f"node {i}: maximal {o.maximal:b} vs {h.maximal_grade_mask:b}"
+        assert o.minimal == h.minimal_grade_mask, f"node {i}: minimal {o.minimal:b} vs {h.minimal_grade_mask:b}"
+        assert o.vec_space_dim == h.vec_space_dim
+        assert o.num_uses == h.num_uses, f"node {i}: num_uses"
+        assert o.n_comp_muls == h.n_comp_muls, f"node {i}: {o.n_comp_muls} vs {h.n_comp_muls} comp muls"
+        if o.n_comp_muls:
+            hm = hspec.comp_muls(i)
+            if hm is not None:
+                assert ospec.comp_muls(i) == hm, f"node {i}: comp-mul lists differ"
