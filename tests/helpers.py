@@ -130,3 +130,49 @@ def assert_same_ast(ospec, hspec):
             hm = hspec.comp_muls(i)
             if hm is not None:
                 assert ospec.comp_muls(i) == hm, f"node {i}: comp-mul lists differ"
+
+
+# ----------------------------------------------------------------------------------------------
+# Independent second method: the product as a twisted XOR-convolution in blade
+# bitmask space, no table, no per-grade indexing.  Used to cross-check the oracle on CPU and as
+# the size-independent checker for dimensions where the oracle's 4^n table is too slow to build.
+# ----------------------------------------------------------------------------------------------
+_POP16 = np.array([bin(i).count("1") for i in range(1 << 16)], dtype=np.int64)
+
+
+def blades_in_row_order(n, grades):
+    """bitmask of every component of a graded row (grades ascending, colex = numeric order)."""
+    out = []
+    for k in sorted(grades):
+        out.extend(m for m in range(1 << n) if _POP16[m] == k)
+    return np.array(out, dtype=np.int64)
+
+
+def row_to_bits(n, grades, row):
+    v = np.zeros(1 << n, dtype=np.float64)
+    v[blades_in_row_order(n, grades)] = np.asarray(row, dtype=np.float64)
+    return v
+
+
+def bits_to_row(n, grades, bits):
+    return bits[blades_in_row_order(n, grades)]
+
+
+def gp_bits(n, metric_diag, A, B, absolute=False):
+    """C[a^b] += s(a,b) * prod(metric over a&b) * A[a] * B[b] over all blade pairs.
+    absolute=True returns sum |term| per output blade (for error bounds)."""
+    N = 1 << n
+    a = np.arange(N, dtype=np.int64)[:, None]
+    b = np.arange(N, dtype=np.int64)[None, :]
+    par = np.zeros((N, N), dtype=np.int64)
+    for s in range(1, n):
+        par += _POP16[(a >> s) & b]
+    coef = np.where(par & 1, -1.0, 1.0)
+    shared = a & b
+    for i, g in enumerate(metric_diag):
+        if g != 1.0:
+            coef = coef * np.where((shared >> i) & 1, float(g), 1.0)
+    terms = coef * np.asarray(A, dtype=np.float64)[:, None] * np.asarray(B, dtype=np.float64)[None, :]
+    if absolute:
+        terms = np.abs(terms)
+    return np.bincount((a ^ b).ravel(), weights=terms.ravel(), minlength=N)
