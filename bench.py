@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r8|cl41]
+
+A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
+multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
+north-star target is quoted on: full multivector x full multivector geometric product in R^12
+(4096 components, 4^12 component multiplies), f32, 65,536 input sets per GPU.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank evaluates its own shard of
+the batch (independent items, no data-path collective): weak scaling.  The RCCL gather of
+the result shards to rank 0 is timed separately and reported beside the main number.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel, timed with HIP
+events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle (the C
+restatement of the reference's src/eval.rs loop) timed on this host on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+PEAK_FP64_TFLOPS = 78.6
+PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
+
+
+def workload_spec(name):
+    """(n, metric, dtype name, builder, input grade lists, label)"""
+    import gaast_amd as ga
+    if name == "r12":
+        n = 12
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F32, dtname="f32", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=65536,
+                    label="R^12 full MV x MV geometric product, f32 (BASELINE configs[2])")
+    if name == "r8":
+        n = 8
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F32, dtname="f32", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=1 << 20,
+                    label="R^8 full MV x MV geometric product, f32 (BASELINE configs[1])")
+    if name == "cl41":
+        return dict(n=5, metric=[1.0, 1.0, 1.0, 1.0, -1.0], dtype=ga.F64, dtname="f64",
+                    inputs=[[0, 2, 4], [1]], build=lambda r, x: r * x * r.rev(), entries=80 + 256,
+                    default_batch=1 << 22,
+                    label="R^{4,1} rotor sandwich R X ~R, f64 (BASELINE configs[4])")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """Time the oracle (literal eval.rs loop, 56-byte AoS table, 1 thread) on a bounded sample."""
+    import numpy as np
+    from oracle import pyoracle as og
+    n = wl["n"]
+    rng = np.random.default_rng(0)
+    L = og.lib()
+    note = ""
+    grades_a = wl["inputs"][0]
+    scale = 1.0
+    if wl["entries"] > (1 << 22):
+        # The full table is 4^n x 56 B (940 MB at n = 12).  The reference orders it by left grade
+        # first (specialize.rs:162-183), so restricting the LEFT operand to grades 0..4 makes the
+        # oracle build exactly the leading slice of that table; time scales with entries.
+        grades_a = [k for k in grades_a if k <= 4]
+        sub = sum(L.og_n_choose_k(n, k) for k in grades_a) * (1 << n)
+        scale = wl["entries"] / sub
+        note = f"leading {sub} of {wl['entries']} table entries (left grades 0..4), time scaled x{scale:.3f}; "
+    def val(grades):
+        return og.GradeMapMV({k: rng.uniform(-1, 1, L.og_n_choose_k(n, k)) for k in grades})
+    a, b = val(grades_a), val(wl["inputs"][1])
+    t0 = time.time()
+    spec = wl["build"](og.mv(a), og.mv(b)).specialize(og.as_algebra(wl["metric"] if any(m != 1.0 for m in wl["metric"]) else n))
+    t_spec = time.time() - t0
+    t0 = time.time()
+    spec.eval()
+    t1 = time.time() - t0
+    items = max(2, min(4096, int(budget_s / max(t1, 1e-6))))
+    t0 = time.time()
+    for _ in range(items):
+        spec.eval()
+    dt = (time.time() - t0) / items
+    per_item = dt * scale
+    import multiprocessing
+    return {"value": 1.0 / per_item, "unit": "products/s", "cores": 1, "kind": "port",
+            "sample": note + f"{items} evaluations of the oracle's eval.rs loop (f64, 56-byte AoS entries, "
+                             f"per-eval allocations included), {dt * 1e3:.2f} ms each; table build {t_spec:.1f} s excluded; "
+                             f"host has {multiprocessing.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="r12")
+    ap.add_argument("--batch", type=int, default=0, help="input sets per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gaast_amd as ga
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    ga.init_device(local_rank)
+    stream = torch.cuda.current_stream()
+    ga._lib.check(ga.lib().gaast_hip_set_stream(C.c_void_p(stream.cuda_stream)))
+
+    wl = workload_spec(args.workload)
+    n, dtype = wl["n"], wl["dtype"]
+    batch = args.batch or wl["default_batch"]
+    tdt = torch.float32 if dtype == ga.F32 else torch.float64
+
+    # one SpecializedAst (phases 1-3 on the host, once), one device program
+    exprs = [ga.mv(ga.Input(s, g, n)) for s, g in enumerate(wl["inputs"])]
+    t0 = time.time()
+    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype)
+    spec.program()
+    t_spec = time.time() - t0
+    out_mask, out_len = spec.output_info()
+
+    # synthetic inputs, generated on the device: item i of rank r is seeded by (seed, r)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3 + rank)
+    ins, in_t = [], []
+    for g in wl["inputs"]:
+        rl = ga.graded.row_len(n, ga.graded._mask_of(g))
+        t = torch.rand((batch, rl), generator=gen, device=dev, dtype=tdt) * 2 - 1
+        in_t.append(t)
+        ins.append(ga.DeviceMV.wrap_tensor(t, n, g))
+    out_t = torch.empty((batch, out_len), device=dev, dtype=tdt)
+    out = ga.DeviceMV.wrap_tensor(out_t, n, ga.GradeSet(out_mask))
+
+    def step():
+        spec.eval_batch(ins, batch, out=out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    fence()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    kernel_ms = sum(step_ms) / len(step_ms)
+
+    # final gather of the result shards to rank 0 over RCCL (xGMI), outside the timed region
+    gather_ms = None
+    if world > 1 and not args.no_gather:
+        glist = [torch.empty_like(out_t) for _ in range(world)] if rank == 0 else None
+        fence()
+        g0 = time.perf_counter()
+        dist.gather(out_t, glist, dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        del glist
+
+    if rank == 0:
+        items_total = batch * world * args.steps
+        value = items_total / wall
+        sz = 4 if dtype == ga.F32 else 8
+        in_len = sum(t.shape[1] for t in in_t)
+        bytes_item = (in_len + out_len) * sz          # every input/output component touched once
+        flops_item = 2 * wl["entries"]                # one multiply + one add per comp-mul entry
+        launches = spec.launches()
+        dense = any("product_dense" in l for l in launches)
+        peak_tf = PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS
+        ach_tf = flops_item * batch / (kernel_ms * 1e-3) * 1e-12
+        ach_gb = bytes_item * batch / (kernel_ms * 1e-3) * 1e-9
+        if dense:
+            roof = {"bound": "mfma", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
+                    "traffic": None,
+                    "note": "dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); "
+                            f"algorithmic HBM {ach_gb:.1f} GB/s = {ach_gb / PEAK_HBM_GBPS:.4f} of 8 TB/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
+                    "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
+        roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
+        roof["kernel_ms"] = kernel_ms
+        roof["flops_per_item"] = flops_item
+        roof["bytes_per_item"] = bytes_item
+        res = {
+            "metric": "full-MV geometric products/sec (dim n); achieved HBM GB/s vs roofline",
+            "value": value, "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": wl["dtname"], "data": "synthetic",
+            "config": {"workload": wl["label"], "dim": n, "batch_per_gpu": batch, "global_batch": batch * world,
+                       "launches_per_eval": launches, "specialize_s": t_spec},
+            "roofline": roof,
+        }
+        if gather_ms is not None:
+            out_bytes = out_len * sz * batch
+            res["gather"] = {"ms": gather_ms, "bytes_per_rank": out_bytes,
+                             "value_with_gather": items_total / (wall + gather_ms * 1e-3 * args.steps)}
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
