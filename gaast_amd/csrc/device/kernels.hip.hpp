@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace gaast {
 
@@ -196,6 +197,7 @@ __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { retur
 template <>
 __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// ---- 16x16 block product, generic (used for f64): 256 scalar FMAs with folded signs ----------
 template <typename T, bool ODD>
 __device__ __forceinline__ void gp_block16(const T (&A)[16], const T (&B)[16], T (&C)[16]) {
 #pragma unroll
@@ -208,44 +210,142 @@ __device__ __forceinline__ void gp_block16(const T (&A)[16], const T (&B)[16], T
     }
 }
 
+// ---- 16x16 block product, f32: 128 v_pk_fma_f32, no operand shuffles ---------------------------
+// Accumulator pair j holds C[2j], C[2j+1].  For the term with left component a, the low half
+// needs B[a ^ 2j] and the high half B[a ^ 2j ^ 1]: the two halves of ONE B pair, swapped when a
+// is odd; A[a] is one half of an A pair, broadcast.  op_sel / op_sel_hi pick the halves and
+// neg_lo / neg_hi carry the compile-time signs, so every FMA is a single instruction.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+template <int X, int NL, int NH>
+__device__ __forceinline__ void pk_fma_sel(float2v& c, const float2v& a, const float2v& b) {
+    if constexpr (X == 0 && NL == 0 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 1 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 0 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 1 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 0 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 1 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 0 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <bool ODD, int IDX>
+__device__ __forceinline__ void gp_block16_pk(const float2v (&A2)[8], const float2v (&B2)[8], float2v (&C2)[8]) {
+    if constexpr (IDX < 128) {
+        constexpr int a = IDX >> 3, j = IDX & 7, c0 = 2 * j;
+        constexpr int b_lo = a ^ c0, b_hi = a ^ c0 ^ 1;
+        constexpr int nl = lo_reorder_parity(a, b_lo) ^ (ODD ? (__builtin_popcount(b_lo) & 1) : 0);
+        constexpr int nh = lo_reorder_parity(a, b_hi) ^ (ODD ? (__builtin_popcount(b_hi) & 1) : 0);
+        pk_fma_sel<(a & 1), nl, nh>(C2[j], A2[a >> 1], B2[b_lo >> 1]);
+        gp_block16_pk<ODD, IDX + 1>(A2, B2, C2);
+    }
+}
+
+// one a_hi step for a lane: load the blocks, apply the block sign, 256 multiply-adds
 template <typename T>
-struct Vec4 {
-    T x, y, z, w;
+struct BlockStep;
+
+template <>
+struct BlockStep<float> {
+    float2v C2[8];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) C2[i] = float2v{0.f, 0.f};
+    }
+    template <bool ODD>
+    __device__ __forceinline__ void step(const float* As, const float* Bs, int a_hi, int b_hi, float sgn) {
+        const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
+        const float4v* ap = reinterpret_cast<const float4v*>(As + (a_hi << 4));
+        const float4v* bp = reinterpret_cast<const float4v*>(Bs + (b_hi << 4));
+        float2v A2[8], B2[8];
+        const float2v s2 = float2v{sgn, sgn};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v va = ap[q ^ sa];
+            const float4v vb = bp[q ^ sb];
+            A2[2 * q] = float2v{va.x, va.y};
+            A2[2 * q + 1] = float2v{va.z, va.w};
+            B2[2 * q] = float2v{vb.x, vb.y} * s2;
+            B2[2 * q + 1] = float2v{vb.z, vb.w} * s2;
+        }
+        gp_block16_pk<ODD, 0>(A2, B2, C2);
+    }
+    __device__ __forceinline__ float get(int i) const { return (i & 1) ? C2[i >> 1].y : C2[i >> 1].x; }
 };
 
-template <typename T, bool DEGENERATE>
-__global__ __launch_bounds__(512) void k_gp_dense(DenseArgs<T> p) {
+template <>
+struct BlockStep<double> {
+    double C[16];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) C[i] = 0.0;
+    }
+    template <bool ODD>
+    __device__ __forceinline__ void step(const double* As, const double* Bs, int a_hi, int b_hi, double sgn) {
+        const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
+        // a "quad" is 4 components = two 16-byte halves for f64
+        const double2v* ap = reinterpret_cast<const double2v*>(As + (a_hi << 4));
+        const double2v* bp = reinterpret_cast<const double2v*>(Bs + (b_hi << 4));
+        double A[16], B[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2v a0 = ap[2 * (q ^ sa)], a1 = ap[2 * (q ^ sa) + 1];
+            const double2v b0 = bp[2 * (q ^ sb)], b1 = bp[2 * (q ^ sb) + 1];
+            A[4 * q + 0] = a0.x; A[4 * q + 1] = a0.y; A[4 * q + 2] = a1.x; A[4 * q + 3] = a1.y;
+            B[4 * q + 0] = b0.x * sgn; B[4 * q + 1] = b0.y * sgn; B[4 * q + 2] = b1.x * sgn; B[4 * q + 3] = b1.y * sgn;
+        }
+        gp_block16<double, ODD>(A, B, C);
+    }
+    __device__ __forceinline__ double get(int i) const { return C[i]; }
+};
+
+template <typename T, bool DEGENERATE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int n = p.n;
     const int N = 1 << n;
     const int hbits = n - 4;
     const int LPI = 1 << hbits;                   // lanes per item
-    const int IPB = blockDim.x >> hbits;          // items per block (>= 1)
-    const int item_stride = 2 * N + 4;            // +16 B: de-phase the items' A broadcasts
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int IPB = THREADS >> hbits;             // items per block (>= 1)
+    const int item_stride = 2 * N + (IPB > 1 ? 4 : 0);  // +16 B: de-phase the items' A broadcasts
+    const int tid = threadIdx.x;
     const int64_t item0 = int64_t(blockIdx.x) * IPB;
     const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
     const T zero = T(0);
 
     // ---- stage both operands of every item of the block, in bitmask order ----
     if (!p.left_full || !p.right_full) {
-        for (int i = tid; i < nitems * item_stride; i += nthr) smem[i] = zero;
+        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
         __syncthreads();
     }
-    for (int i = tid; i < nitems * p.left_count; i += nthr) {
-        const int it = i / p.left_count, j = i - it * p.left_count;
-        const uint32_t m = p.left_map[j];
-        T v = p.left[(item0 + it) * p.left_stride + (m & 0xffffu)];
-        if (p.canon_left) v = zero + v;
-        smem[it * item_stride + dense_lds_pos(int(m >> 16))] = v;
-    }
-    for (int i = tid; i < nitems * p.right_count; i += nthr) {
-        const int it = i / p.right_count, j = i - it * p.right_count;
-        const uint32_t m = p.right_map[j];
-        T v = p.right[(item0 + it) * p.right_stride + (m & 0xffffu)];
-        if (p.canon_right) v = zero + v;
-        smem[it * item_stride + N + dense_lds_pos(int(m >> 16))] = v;
+    for (int it = 0; it < nitems; ++it) {
+        const T* lrow = p.left + (item0 + it) * p.left_stride;
+        const T* rrow = p.right + (item0 + it) * p.right_stride;
+        T* as = smem + it * item_stride;
+        T* bs = as + N;
+        for (int j = tid; j < p.left_count; j += THREADS) {
+            const uint32_t m = p.left_map[j];
+            T v = lrow[m & 0xffffu];
+            if (p.canon_left) v = zero + v;
+            as[dense_lds_pos(int(m >> 16))] = v;
+        }
+        for (int j = tid; j < p.right_count; j += THREADS) {
+            const uint32_t m = p.right_map[j];
+            T v = rrow[m & 0xffffu];
+            if (p.canon_right) v = zero + v;
+            bs[dense_lds_pos(int(m >> 16))] = v;
+        }
     }
     __syncthreads();
 
@@ -254,11 +354,14 @@ __global__ __launch_bounds__(512) void k_gp_dense(DenseArgs<T> p) {
     if (it < nitems) {
         const T* As = smem + it * item_stride;
         const T* Bs = As + N;
-        T C[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) C[i] = zero;
+        BlockStep<T> acc;
+        acc.init();
 
-        for (int a_hi = 0; a_hi < LPI; ++a_hi) {
+        // Two passes: first the A blocks with |a_hi| even, then those with |a_hi| odd -- each pass
+        // has ONE straight-line body (the sign pattern of the 16x16 block depends on that parity),
+        // so the accumulators never cross a branch.  a_hi = 2i + (parity(i) ^ pass).
+        auto one_step = [&](auto odd_tag, int a_hi) {
+            constexpr bool ODD = decltype(odd_tag)::value;
             // wave-uniform part of the block sign
             uint32_t sp = uint32_t(a_hi) >> 1;
             sp ^= sp >> 1;
@@ -274,24 +377,11 @@ __global__ __launch_bounds__(512) void k_gp_dense(DenseArgs<T> p) {
             if (DEGENERATE) {
                 if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) sgn = zero;
             }
-            const int b_hi = a_hi ^ c_hi;
-            const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
-            const Vec4<T>* ap = reinterpret_cast<const Vec4<T>*>(As + (a_hi << 4));
-            const Vec4<T>* bp = reinterpret_cast<const Vec4<T>*>(Bs + (b_hi << 4));
-            T A[16], B[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const Vec4<T> va = ap[q ^ sa];
-                const Vec4<T> vb = bp[q ^ sb];
-                A[4 * q + 0] = va.x; A[4 * q + 1] = va.y; A[4 * q + 2] = va.z; A[4 * q + 3] = va.w;
-                B[4 * q + 0] = vb.x * sgn; B[4 * q + 1] = vb.y * sgn;
-                B[4 * q + 2] = vb.z * sgn; B[4 * q + 3] = vb.w * sgn;
-            }
-            if (__builtin_popcount(uint32_t(a_hi)) & 1)
-                gp_block16<T, true>(A, B, C);
-            else
-                gp_block16<T, false>(A, B, C);
-        }
+            acc.template step<ODD>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
+        };
+        const int half = LPI >> 1;
+        for (int i = 0; i < half; ++i) one_step(std::false_type{}, (i << 1) | (__builtin_popcount(uint32_t(i)) & 1));
+        for (int i = 0; i < half; ++i) one_step(std::true_type{}, (i << 1) | ((__builtin_popcount(uint32_t(i)) & 1) ^ 1));
 
         // ---- scatter the 16 accumulators to their positions in the graded row ----
         T* orow = p.out + (item0 + it) * p.out_stride;
@@ -299,7 +389,7 @@ __global__ __launch_bounds__(512) void k_gp_dense(DenseArgs<T> p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int32_t off = om[i];
-            if (off >= 0) orow[off] = p.beta ? orow[off] + C[i] : C[i];
+            if (off >= 0) orow[off] = p.beta ? orow[off] + acc.get(i) : acc.get(i);
         }
     }
 }

@@ -200,10 +200,11 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         const int lpi = 1 << (n - 4);
         const int threads = lpi > 256 ? lpi : 256;
         const int ipb = threads / lpi;
-        const size_t lds = size_t(ipb) * size_t(2 * (1 << n) + 4) * sizeof(T);
+        const size_t lds = size_t(ipb) * size_t(2 * (1 << n) + (ipb > 1 ? 4 : 0)) * sizeof(T);
         if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
         const int64_t blocks = (batch + ipb - 1) / ipb;
-        auto kern = s.degenerate ? &k_gp_dense<T, true> : &k_gp_dense<T, false>;
+        auto kern = threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256> : &k_gp_dense<T, false, 256>)
+                                   : (s.degenerate ? &k_gp_dense<T, true, 512> : &k_gp_dense<T, false, 512>);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));

