@@ -134,6 +134,170 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Whole-AST kernel for small (grade-sparse) programs: ONE launch per evaluation.
+//
+// lane <-> batch item.  Every buffer of the plan (the bound inputs that are read, the cache
+// buffers of the product operands, the root result) lives in LDS as one "slab" of S elements
+// per item; S is odd so that the 64 lanes of a wave reading the same slab offset touch 64
+// different banks.  Inputs are copied HBM -> LDS with coalesced loads (a block's rows are one
+// contiguous range), the result goes back the same way: HBM traffic is exactly the inputs
+// once plus the root once.  In between each lane runs the plan as a stream of micro-ops read
+// through the scalar cache (the stream is wave-uniform), in the reference's order:
+// every arm of eval.rs is one micro-op kind, and a Product is its comp-mul list grouped by
+// result component with each component's entries in the reference's order, so all roundings
+// are those of eval.rs:82.
+//
+// micro-op word: [31:28] opcode
+//   MAC  l[11:0] r[23:12] c[26:24]   acc = acc + (slab[l] * slab[r]) * coeff(c)   c: 0 -> +1, 1 -> -1, >= 2 -> table[c-2]
+//   ROW  dst[11:0] fresh[12]         acc = fresh ? 0.0 : slab[dst]
+//   ST   dst[11:0]                   slab[dst] = acc
+//   ADD  dst[11:0] src[23:12]        slab[dst] = slab[dst] + slab[src]            (graded.rs:74)
+//   NEG  dst[11:0]                   slab[dst] = -slab[dst]                        (graded.rs:63)
+//   ZERO dst[11:0] count[23:12]      slab[dst .. dst+count) = 0.0                  (graded.rs:195-201)
+//   INV / SQRT dst[11:0]             eval.rs:106-109
+//   NOP
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { UOP_MAC = 0, UOP_ROW = 1, UOP_ST = 2, UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5,
+                  UOP_INV = 6, UOP_SQRT = 7, UOP_NOP = 8 };
+
+constexpr int FUSED_MAX_INPUTS = 8;
+constexpr int FUSED_THREADS = 64;
+
+template <typename T>
+struct FusedArgs {
+    const uint32_t* prog;   // micro-ops, padded with NOPs to a multiple of 8 words
+    int n_words;
+    T coeff[6];             // general coefficients (c >= 2)
+    int slab;               // S: elements per item, odd
+    int n_in;
+    const T* in_ptr[FUSED_MAX_INPUTS];
+    int64_t in_stride[FUSED_MAX_INPUTS];
+    int in_len[FUSED_MAX_INPUTS];
+    int in_base[FUSED_MAX_INPUTS];
+    int in_canon[FUSED_MAX_INPUTS];  // apply 0.0 + x while staging (input only read as a product operand)
+    T* out_ptr;
+    int64_t out_stride;
+    int out_len, out_base;
+    int64_t batch;
+};
+
+template <typename T>
+__device__ __forceinline__ T sqrt_t(T x);
+template <>
+__device__ __forceinline__ float sqrt_t<float>(float x) { return __builtin_sqrtf(x); }
+template <>
+__device__ __forceinline__ double sqrt_t<double>(double x) { return __builtin_sqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ void fused_exec(uint32_t w, T* __restrict__ my, T& acc, const FusedArgs<T>& p) {
+    const uint32_t op = w >> 28;
+    if (op == UOP_MAC) {
+        const T t = my[w & 0xfffu] * my[(w >> 12) & 0xfffu];
+        const uint32_t c = (w >> 24) & 7u;
+        if (c == 0)
+            acc = acc + t;
+        else if (c == 1)
+            acc = acc - t;  // (l*r)*(-1.0) added: exact
+        else
+            acc = acc + t * p.coeff[c - 2];
+    } else if (op == UOP_ROW) {
+        acc = ((w >> 12) & 1u) ? T(0) : my[w & 0xfffu];
+    } else if (op == UOP_ST) {
+        my[w & 0xfffu] = acc;
+    } else if (op == UOP_ADD) {
+        T* d = my + (w & 0xfffu);
+        *d = *d + my[(w >> 12) & 0xfffu];
+    } else if (op == UOP_NEG) {
+        T* d = my + (w & 0xfffu);
+        *d = -*d;
+    } else if (op == UOP_ZERO) {
+        const uint32_t d = w & 0xfffu, cnt = (w >> 12) & 0xfffu;
+        for (uint32_t i = 0; i < cnt; ++i) my[d + i] = T(0);
+    } else if (op == UOP_INV) {
+        T* d = my + (w & 0xfffu);
+        *d = T(1) / *d;
+    } else if (op == UOP_SQRT) {
+        T* d = my + (w & 0xfffu);
+        *d = sqrt_t<T>(*d);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int S = p.slab;
+    const int64_t item0 = int64_t(blockIdx.x) * FUSED_THREADS;
+    const int nitems = int(p.batch - item0 < FUSED_THREADS ? p.batch - item0 : FUSED_THREADS);
+
+    // ---- stage the inputs: element e of the block's contiguous row range -> (item, comp) ----
+    for (int s = 0; s < p.n_in; ++s) {
+        const int len = p.in_len[s];
+        if (len <= 0) continue;
+        const T* src = p.in_ptr[s] + item0 * p.in_stride[s];
+        const int total = nitems * len;
+        int it = tid / len, c = tid - it * len;
+        const int dit = FUSED_THREADS / len, dc = FUSED_THREADS - dit * len;
+        for (int e = tid; e < total; e += FUSED_THREADS) {
+            T v = src[int64_t(it) * p.in_stride[s] + c];
+            if (p.in_canon[s]) v = T(0) + v;
+            smem[it * S + p.in_base[s] + c] = v;
+            it += dit;
+            c += dc;
+            if (c >= len) {
+                c -= len;
+                ++it;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- run the plan on this lane's item ----
+    T* my = smem + tid * S;
+    T acc = T(0);
+    const uint4* prog4 = reinterpret_cast<const uint4*>(p.prog);
+    const int n_chunks = p.n_words >> 3;
+    uint4 a = prog4[0], b = prog4[1];
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        uint4 na = a, nb = b;
+        if (ch + 1 < n_chunks) {  // prefetch the next 8 micro-ops (scalar loads) behind these
+            na = prog4[2 * ch + 2];
+            nb = prog4[2 * ch + 3];
+        }
+        fused_exec<T>(a.x, my, acc, p);
+        fused_exec<T>(a.y, my, acc, p);
+        fused_exec<T>(a.z, my, acc, p);
+        fused_exec<T>(a.w, my, acc, p);
+        fused_exec<T>(b.x, my, acc, p);
+        fused_exec<T>(b.y, my, acc, p);
+        fused_exec<T>(b.z, my, acc, p);
+        fused_exec<T>(b.w, my, acc, p);
+        a = na;
+        b = nb;
+    }
+    __syncthreads();
+
+    // ---- write the root result rows back, coalesced ----
+    {
+        const int len = p.out_len;
+        T* dst = p.out_ptr + item0 * p.out_stride;
+        const int total = nitems * len;
+        int it = tid / len, c = tid - it * len;
+        const int dit = FUSED_THREADS / len, dc = FUSED_THREADS - dit * len;
+        for (int e = tid; e < total; e += FUSED_THREADS) {
+            dst[int64_t(it) * p.out_stride + c] = smem[it * S + p.out_base + c];
+            it += dit;
+            c += dc;
+            if (c >= len) {
+                c -= len;
+                ++it;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Product arm, dense geometric product, tiled in blade-bitmask space.
 //
 // In bitmask space e_a e_b = s(a,b) m(a&b) e_{a^b}  (algebra.rs:73-83), a twisted

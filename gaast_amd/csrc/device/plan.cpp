@@ -14,6 +14,7 @@
 //       keeps them on the exact kernel).
 #include "plan.hpp"
 
+#include <cstring>
 #include <map>
 #include <stdexcept>
 
@@ -357,6 +358,131 @@ struct Lowering {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Whole-plan fusion for small programs: every buffer becomes a region of a per-item LDS slab and
+// the steps become one micro-op stream (k_ast_fused).  Exact: same operations, same order.
+// ---------------------------------------------------------------------------------------------
+bool try_fuse(Plan& plan) {
+    if (plan.flags & GAAST_FLAG_NO_FUSION) return false;
+    if (plan.error != GAAST_OK || plan.steps.empty()) return false;
+    const size_t elem = plan.dtype == GAAST_F32 ? 4 : 8;
+    // which buffers are touched, and how inputs are read
+    std::vector<int> in_direct(plan.inputs.size(), 0), in_axpy(plan.inputs.size(), 0);
+    for (const Step& s : plan.steps) {
+        if (s.kind == Step::PRODUCT_DENSE || s.kind == Step::FUSED) return false;
+        if (s.kind == Step::AXPY) in_axpy[size_t(s.a.idx)] = 1;
+        if (s.kind == Step::PRODUCT_CSR) {
+            if (s.a.kind == BufKind::INPUT) (s.canon_a ? in_direct : in_axpy)[size_t(s.a.idx)] = 1;
+            if (s.b.kind == BufKind::INPUT) (s.canon_b ? in_direct : in_axpy)[size_t(s.b.idx)] = 1;
+        }
+    }
+    Step f;
+    f.kind = Step::FUSED;
+    f.res = BufRef{BufKind::OUT, 0};
+    int cursor = 0;
+    // an input read both ways gets two images: the raw rows (add_grades_from) and 0.0 + x
+    // (the zero-init + copy the reference makes of a product operand)
+    std::vector<int> in_base(plan.inputs.size(), -1), in_base_canon(plan.inputs.size(), -1);
+    std::vector<int> node_base(plan.node_buffers.size(), -1);
+    for (size_t i = 0; i < plan.inputs.size(); ++i) {
+        if (plan.input_layouts[i].row_len == 0) continue;
+        if (in_axpy[i]) {
+            in_base[i] = cursor;
+            f.fused_inputs.push_back({int(i), cursor, 0});
+            cursor += int(plan.input_layouts[i].row_len);
+        }
+        if (in_direct[i]) {
+            in_base_canon[i] = cursor;
+            f.fused_inputs.push_back({int(i), cursor, 1});
+            cursor += int(plan.input_layouts[i].row_len);
+        }
+    }
+    if (f.fused_inputs.size() > size_t(uop::MAX_INPUTS)) return false;
+    for (size_t i = 0; i < plan.node_buffers.size(); ++i) {
+        node_base[i] = cursor;
+        cursor += int(plan.node_buffers[i].row_len);
+    }
+    const int out_base = cursor;
+    cursor += int(plan.out_layout.row_len);
+    if (plan.out_layout.row_len == 0) return false;
+    int slab = cursor | 1;  // odd: 64 lanes at one slab offset hit 64 different banks
+    if (slab > 4095 || size_t(slab) * elem * 64 > 48 * 1024) return false;
+    auto base_of = [&](BufRef r, int canon = 0) {
+        return r.kind == BufKind::NODE    ? node_base[size_t(r.idx)]
+               : r.kind == BufKind::INPUT ? (canon ? in_base_canon : in_base)[size_t(r.idx)]
+                                          : out_base;
+    };
+    auto layout_of = [&](BufRef r) -> const Layout& {
+        return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)]
+               : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)] : plan.out_layout;
+    };
+    std::vector<uint32_t>& prog = f.u32_a;
+    auto op = [](uint32_t code, uint32_t lo, uint32_t mid = 0, uint32_t c = 0) {
+        return (code << 28) | (c << 24) | (mid << 12) | lo;
+    };
+    std::vector<double>& general = f.coeff;
+    uint64_t entries = 0;
+    for (const Step& s : plan.steps) {
+        const uint32_t rb = uint32_t(base_of(s.res));
+        switch (s.kind) {
+        case Step::ZERO:
+            if (layout_of(s.res).row_len) prog.push_back(op(uop::ZERO, rb, uint32_t(layout_of(s.res).row_len)));
+            break;
+        case Step::AXPY:
+            for (uint32_t m : s.u32_a) prog.push_back(op(uop::ADD, rb + (m & 0xffffu), uint32_t(base_of(s.a)) + (m >> 16)));
+            break;
+        case Step::FLIP:
+            for (uint32_t o : s.u32_a) prog.push_back(op(uop::NEG, rb + o));
+            break;
+        case Step::SUNARY:
+            prog.push_back(op(s.sunary_op == 0 ? uop::INV : uop::SQRT, rb + uint32_t(s.sunary_off)));
+            break;
+        case Step::PRODUCT_CSR: {
+            const uint32_t lb = uint32_t(base_of(s.a, s.canon_a)), rrb = uint32_t(base_of(s.b, s.canon_b));
+            for (size_t row = 0; row + 1 < s.u32_a.size(); ++row) {
+                const uint32_t dst = rb + s.u32_b[row];
+                prog.push_back(op(uop::ROW, dst, s.beta ? 0u : 1u));
+                for (uint32_t e = s.u32_a[row]; e < s.u32_a[row + 1]; ++e) {
+                    const double c = s.coeff[e];
+                    uint32_t ci;
+                    if (c == 1.0) {
+                        ci = 0;
+                    } else if (c == -1.0) {
+                        ci = 1;
+                    } else {
+                        size_t g = 0;
+                        for (; g < general.size(); ++g)
+                            if (std::memcmp(&general[g], &c, sizeof(double)) == 0) break;
+                        if (g == general.size()) {
+                            if (general.size() == size_t(uop::MAX_GENERAL_COEFFS)) return false;
+                            general.push_back(c);
+                        }
+                        ci = uint32_t(g) + 2;
+                    }
+                    prog.push_back(op(uop::MAC, lb + (s.u32_c[e] & 0xffffu), rrb + (s.u32_c[e] >> 16), ci));
+                    ++entries;
+                }
+                prog.push_back(op(uop::ST, dst));
+            }
+            break;
+        }
+        default: return false;
+        }
+    }
+    if (prog.size() > (1u << 16)) return false;
+    while (prog.size() % 8 != 0 || prog.empty()) prog.push_back(op(uop::NOP, 0));
+    f.fused_slab = slab;
+    f.fused_out_base = out_base;
+    f.n_entries = entries;
+    f.name = "ast_fused[" + std::to_string(plan.steps.size()) + " arms, " + std::to_string(entries) +
+             " comp-muls, slab " + std::to_string(slab) + "]";
+    plan.steps.clear();
+    plan.steps.push_back(std::move(f));
+    plan.node_buffers.clear();  // the cache buffers live in LDS now
+    return true;
+}
+
 }  // namespace
 
 void build_plan(const gaast_program_desc& desc, Plan& plan) {
@@ -414,6 +540,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
     for (size_t i = 0; i < plan.steps.size(); ++i)
         if (!lw.removed[i]) kept.push_back(std::move(plan.steps[i]));
     plan.steps = std::move(kept);
+    try_fuse(plan);
 }
 
 }  // namespace gaast

@@ -35,7 +35,7 @@ inline Layout make_layout(int dim, uint64_t mask) {
 }
 
 struct Step {
-    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE } kind = ZERO;
+    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED } kind = ZERO;
     BufRef res, a, b;
     std::string name;
     // host images of the tables (uploaded once at program_create)
@@ -43,6 +43,7 @@ struct Step {
     std::vector<uint32_t> u32_b;   // CSR row_out | DENSE right_map
     std::vector<uint32_t> u32_c;   // CSR entries
     std::vector<double> coeff;     // CSR coefficients (converted to the program dtype on upload)
+    std::vector<double> coeff_host; // FUSED: the general coefficients, passed by value at launch
     std::vector<int32_t> i32_a;    // DENSE out_map
     int sunary_op = 0, sunary_off = 0;
     int canon_a = 0, canon_b = 0;
@@ -51,6 +52,12 @@ struct Step {
     uint32_t neg_hi = 0, zero_hi = 0;
     int degenerate = 0;
     uint64_t n_entries = 0;  // comp-mul count this step stands for
+    // FUSED: the whole plan as one micro-op stream over per-item LDS slabs (u32_a = the stream)
+    struct FusedInput {
+        int slot, base, canon;
+    };
+    std::vector<FusedInput> fused_inputs;
+    int fused_slab = 0, fused_out_base = 0;
     // device copies
     void* d_a = nullptr;
     void* d_b = nullptr;
@@ -76,5 +83,12 @@ struct Plan {
 
 // Throws std::runtime_error (-> GAAST_ERR_INVALID_PROGRAM) on malformed input.
 void build_plan(const gaast_program_desc& desc, Plan& plan);
+
+// Micro-op encoding shared by the plan builder and k_ast_fused (see kernels.hip.hpp).
+namespace uop {
+enum : uint32_t { MAC = 0, ROW = 1, ST = 2, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7, NOP = 8 };
+constexpr int MAX_GENERAL_COEFFS = 6;
+constexpr int MAX_INPUTS = 8;
+}  // namespace uop
 
 }  // namespace gaast

@@ -175,6 +175,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         hipLaunchKernelGGL(k_product_csr<T>, dim3(unsigned(blocks)), dim3(256), lds, g_stream, p);
         break;
     }
+    case Step::FUSED: return GAAST_OK;  // launched by run_fused (needs every bound buffer)
     case Step::PRODUCT_DENSE: {
         DenseArgs<T> p;
         p.left = static_cast<const T*>(a.ptr);
@@ -212,6 +213,35 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         break;
     }
     }
+    HIP_TRY(hipGetLastError());
+    return GAAST_OK;
+}
+
+template <typename T>
+int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound, const Bound& out, int64_t batch) {
+    FusedArgs<T> p;
+    std::memset(&p, 0, sizeof(p));
+    p.prog = static_cast<const uint32_t*>(s.d_a);
+    p.n_words = int(s.u32_a.size());
+    for (size_t i = 0; i < s.coeff_host.size() && i < 6; ++i) p.coeff[i] = T(s.coeff_host[i]);
+    p.slab = s.fused_slab;
+    p.n_in = int(s.fused_inputs.size());
+    for (int i = 0; i < p.n_in; ++i) {
+        const Step::FusedInput& fi = s.fused_inputs[size_t(i)];
+        p.in_ptr[i] = static_cast<const T*>(in_bound[size_t(fi.slot)].ptr);
+        p.in_stride[i] = in_bound[size_t(fi.slot)].stride;
+        p.in_len[i] = int(plan.input_layouts[size_t(fi.slot)].row_len);
+        p.in_base[i] = fi.base;
+        p.in_canon[i] = fi.canon;
+    }
+    p.out_ptr = static_cast<T*>(out.ptr);
+    p.out_stride = out.stride;
+    p.out_len = int(plan.out_layout.row_len);
+    p.out_base = s.fused_out_base;
+    p.batch = batch;
+    const size_t lds = size_t(p.slab) * sizeof(T) * FUSED_THREADS;
+    const int64_t blocks = (batch + FUSED_THREADS - 1) / FUSED_THREADS;
+    hipLaunchKernelGGL(k_ast_fused<T>, dim3(unsigned(blocks)), dim3(FUSED_THREADS), lds, g_stream, p);
     HIP_TRY(hipGetLastError());
     return GAAST_OK;
 }
@@ -278,7 +308,7 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         if (int st = upload_vec(s.u32_b, &s.d_b)) return st;
         if (int st = upload_vec(s.u32_c, &s.d_c)) return st;
         if (int st = upload_vec(s.i32_a, &s.d_i32)) return st;
-        if (!s.coeff.empty()) {
+        if (!s.coeff.empty() && s.kind != Step::FUSED) {
             if (plan.dtype == GAAST_F32) {
                 std::vector<float> cf(s.coeff.begin(), s.coeff.end());
                 if (int st = upload_vec(cf, &s.d_coeff)) return st;
@@ -287,6 +317,7 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
             }
         }
         // the host images of the big tables are no longer needed
+        s.coeff_host = s.kind == Step::FUSED ? s.coeff : std::vector<double>();
         std::vector<uint32_t>().swap(s.u32_c);
         std::vector<double>().swap(s.coeff);
         prog->launch_names.push_back(s.name);
@@ -459,6 +490,8 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n
             bool used = false;
             for (const Step& s : plan.steps)
                 used |= (s.a.kind == BufKind::INPUT && s.a.idx == int(i)) || (s.b.kind == BufKind::INPUT && s.b.idx == int(i));
+            for (const Step& s : plan.steps)
+                for (const Step::FusedInput& fi : s.fused_inputs) used |= fi.slot == int(i);
             if (used) return set_err(GAAST_ERR_INVALID_ARGUMENT, "input slot " + std::to_string(i) + " is not bound");
             continue;
         }
@@ -502,6 +535,12 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n
     for (const Step& s : plan.steps) {
         Layout lres, la, lb;
         const Bound res = resolve(s.res, &lres);
+        if (s.kind == Step::FUSED) {
+            const int st = plan.dtype == GAAST_F32 ? run_fused<float>(s, plan, in_bound, res, batch)
+                                                   : run_fused<double>(s, plan, in_bound, res, batch);
+            if (st != GAAST_OK) return st;
+            continue;
+        }
         if (s.kind == Step::ZERO) {
             if (lres.row_len)
                 HIP_TRY(hipMemset2DAsync(res.ptr, size_t(res.stride) * sz, 0, size_t(lres.row_len) * sz,
