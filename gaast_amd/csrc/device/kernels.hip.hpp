@@ -141,32 +141,40 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 // per item; S is odd so that the 64 lanes of a wave reading the same slab offset touch 64
 // different banks.  Inputs are copied HBM -> LDS with coalesced loads (a block's rows are one
 // contiguous range), the result goes back the same way: HBM traffic is exactly the inputs
-// once plus the root once.  In between each lane runs the plan as a stream of micro-ops read
-// through the scalar cache (the stream is wave-uniform), in the reference's order:
-// every arm of eval.rs is one micro-op kind, and a Product is its comp-mul list grouped by
-// result component with each component's entries in the reference's order, so all roundings
-// are those of eval.rs:82.
+// once plus the root once.  In between each lane runs the plan as a wave-uniform stream of
+// 8-word lines fetched through the scalar cache one line ahead, in the reference's order:
+// a Product is its comp-mul list grouped by result component, each component's entries in
+// the reference's order, so all roundings are those of eval.rs:82.
 //
-// micro-op word: [31:28] opcode
-//   MAC  l[11:0] r[23:12] c[26:24]   acc = acc + (slab[l] * slab[r]) * coeff(c)   c: 0 -> +1, 1 -> -1, >= 2 -> table[c-2]
-//   ROW  dst[11:0] fresh[12]         acc = fresh ? 0.0 : slab[dst]
-//   ST   dst[11:0]                   slab[dst] = acc
-//   ADD  dst[11:0] src[23:12]        slab[dst] = slab[dst] + slab[src]            (graded.rs:74)
-//   NEG  dst[11:0]                   slab[dst] = -slab[dst]                        (graded.rs:63)
-//   ZERO dst[11:0] count[23:12]      slab[dst .. dst+count) = 0.0                  (graded.rs:195-201)
-//   INV / SQRT dst[11:0]             eval.rs:106-109
-//   NOP
+// line = 8 x u32.  word 0 = header, [31:28] kind:
+//   LINE_MACS  dst[11:0] begin[12] fresh[13] end[14] count[17:15]; words 1..7 = MAC slots
+//              begin: acc = fresh ? 0.0 : slab[dst];   end: slab[dst] = acc
+//              MAC slot: l[11:0] r[23:12] c[26:24]:  acc = acc + (slab[l] * slab[r]) * coeff(c)
+//              with coeff(0) = +1, coeff(1) = -1, c >= 2 -> general table[c-2].
+//              LINE_MACS holds only c in {0,1} and applies the sign by flipping the product's
+//              sign bit (identical to multiplying by +-1.0); LINE_MACS_GEN multiplies by the
+//              coefficient like eval.rs:82 does.  The body is straight-line per count: all
+//              operands of a line are fetched before the first multiply.
+//   LINE_MISC  count[17:15]; words 1..count = element-wise micro-ops, [31:28] opcode:
+//              ADD dst[11:0] src[23:12]   slab[dst] = slab[dst] + slab[src]     (graded.rs:74)
+//              NEG dst                    slab[dst] = -slab[dst]                 (graded.rs:63)
+//              ZERO dst count[23:12]      slab[dst..dst+count) = 0.0             (graded.rs:195-201)
+//              INV / SQRT dst             eval.rs:106-109
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { UOP_MAC = 0, UOP_ROW = 1, UOP_ST = 2, UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5,
-                  UOP_INV = 6, UOP_SQRT = 7, UOP_NOP = 8 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3 };
+enum : uint32_t { UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5, UOP_INV = 6, UOP_SQRT = 7 };
 
 constexpr int FUSED_MAX_INPUTS = 8;
-constexpr int FUSED_THREADS = 64;
+constexpr int FUSED_ITEMS = 64;    // items per workgroup: lane <-> item
+constexpr int FUSED_GROUPS = 4;    // waves per workgroup: the independent result rows of a step are
+                                   // dealt to the waves, all working on the same 64 slabs
+constexpr int FUSED_THREADS = FUSED_ITEMS * FUSED_GROUPS;
 
 template <typename T>
 struct FusedArgs {
-    const uint32_t* prog;   // micro-ops, padded with NOPs to a multiple of 8 words
-    int n_words;
+    const uint32_t* prog;      // 8-word lines
+    const uint32_t* phase_tab; // per (phase, wave): first line, number of lines
+    int n_phases;
     T coeff[6];             // general coefficients (c >= 2)
     int slab;               // S: elements per item, odd
     int n_in;
@@ -189,36 +197,70 @@ template <>
 __device__ __forceinline__ double sqrt_t<double>(double x) { return __builtin_sqrt(x); }
 
 template <typename T>
-__device__ __forceinline__ void fused_exec(uint32_t w, T* __restrict__ my, T& acc, const FusedArgs<T>& p) {
+__device__ __forceinline__ void fused_misc(uint32_t w, T* __restrict__ my) {
     const uint32_t op = w >> 28;
-    if (op == UOP_MAC) {
-        const T t = my[w & 0xfffu] * my[(w >> 12) & 0xfffu];
-        const uint32_t c = (w >> 24) & 7u;
-        if (c == 0)
-            acc = acc + t;
-        else if (c == 1)
-            acc = acc - t;  // (l*r)*(-1.0) added: exact
-        else
-            acc = acc + t * p.coeff[c - 2];
-    } else if (op == UOP_ROW) {
-        acc = ((w >> 12) & 1u) ? T(0) : my[w & 0xfffu];
-    } else if (op == UOP_ST) {
-        my[w & 0xfffu] = acc;
-    } else if (op == UOP_ADD) {
-        T* d = my + (w & 0xfffu);
+    T* d = my + (w & 0xfffu);
+    if (op == UOP_ADD) {
         *d = *d + my[(w >> 12) & 0xfffu];
     } else if (op == UOP_NEG) {
-        T* d = my + (w & 0xfffu);
         *d = -*d;
     } else if (op == UOP_ZERO) {
-        const uint32_t d = w & 0xfffu, cnt = (w >> 12) & 0xfffu;
-        for (uint32_t i = 0; i < cnt; ++i) my[d + i] = T(0);
+        const uint32_t cnt = (w >> 12) & 0xfffu;
+        for (uint32_t i = 0; i < cnt; ++i) d[i] = T(0);
     } else if (op == UOP_INV) {
-        T* d = my + (w & 0xfffu);
         *d = T(1) / *d;
     } else if (op == UOP_SQRT) {
-        T* d = my + (w & 0xfffu);
         *d = sqrt_t<T>(*d);
+    }
+}
+
+__device__ __forceinline__ float flip_sign(float t, uint32_t s) {
+    return __uint_as_float(__float_as_uint(t) ^ (s << 31));
+}
+__device__ __forceinline__ double flip_sign(double t, uint32_t s) {
+    return __hiloint2double(__double2hiint(t) ^ int(s << 31), __double2loint(t));
+}
+
+template <typename T, int CNT, bool GENERAL>
+__device__ __forceinline__ void fused_mac_line(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
+                                               const T* __restrict__ ctab) {
+    T l[CNT], r[CNT], cf[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        l[k] = my[w[k] & 0xfffu];
+        r[k] = my[(w[k] >> 12) & 0xfffu];
+        if (GENERAL) cf[k] = ctab[(w[k] >> 24) & 7u];
+    }
+    T* d = my + (h & 0xfffu);
+    if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        const T t = l[k] * r[k];
+        if (GENERAL)
+            acc = acc + t * cf[k];                          // eval.rs:82
+        else
+            acc = acc + flip_sign(t, (w[k] >> 24) & 1u);     // (l*r)*(+-1.0), exact
+    }
+    if (h & (1u << 14)) *d = acc;
+}
+
+template <typename T, bool GENERAL>
+__device__ __forceinline__ void fused_mac_dispatch(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
+                                                   const T* __restrict__ ctab) {
+    switch ((h >> 15) & 7u) {
+    case 0: {  // an empty row: only begin / end
+        T* d = my + (h & 0xfffu);
+        if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
+        if (h & (1u << 14)) *d = acc;
+        break;
+    }
+    case 1: fused_mac_line<T, 1, GENERAL>(h, w, my, acc, ctab); break;
+    case 2: fused_mac_line<T, 2, GENERAL>(h, w, my, acc, ctab); break;
+    case 3: fused_mac_line<T, 3, GENERAL>(h, w, my, acc, ctab); break;
+    case 4: fused_mac_line<T, 4, GENERAL>(h, w, my, acc, ctab); break;
+    case 5: fused_mac_line<T, 5, GENERAL>(h, w, my, acc, ctab); break;
+    case 6: fused_mac_line<T, 6, GENERAL>(h, w, my, acc, ctab); break;
+    default: fused_mac_line<T, 7, GENERAL>(h, w, my, acc, ctab); break;
     }
 }
 
@@ -228,8 +270,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
     const int S = p.slab;
-    const int64_t item0 = int64_t(blockIdx.x) * FUSED_THREADS;
-    const int nitems = int(p.batch - item0 < FUSED_THREADS ? p.batch - item0 : FUSED_THREADS);
+    const int64_t item0 = int64_t(blockIdx.x) * FUSED_ITEMS;
+    const int nitems = int(p.batch - item0 < FUSED_ITEMS ? p.batch - item0 : FUSED_ITEMS);
 
     // ---- stage the inputs: element e of the block's contiguous row range -> (item, comp) ----
     for (int s = 0; s < p.n_in; ++s) {
@@ -251,35 +293,49 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
             }
         }
     }
+    // coefficient table behind the slabs: [+1, -1, general...]
+    T* ctab = smem + FUSED_ITEMS * S;
+    if (tid < 8) ctab[tid] = tid == 0 ? T(1) : tid == 1 ? T(-1) : p.coeff[tid - 2 < 6 ? tid - 2 : 0];
     __syncthreads();
 
-    // ---- run the plan on this lane's item ----
-    T* my = smem + tid * S;
+    // ---- run the plan: this wave's share of every step, on this lane's item ----
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T* my = smem + (tid & 63) * S;
     T acc = T(0);
     const uint4* prog4 = reinterpret_cast<const uint4*>(p.prog);
-    const int n_chunks = p.n_words >> 3;
-    uint4 a = prog4[0], b = prog4[1];
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        uint4 na = a, nb = b;
-        if (ch + 1 < n_chunks) {  // prefetch the next 8 micro-ops (scalar loads) behind these
-            na = prog4[2 * ch + 2];
-            nb = prog4[2 * ch + 3];
+    for (int ph = 0; ph < p.n_phases; ++ph) {
+        const uint32_t first = p.phase_tab[2 * (ph * FUSED_GROUPS + wave)];
+        const int n_lines = int(p.phase_tab[2 * (ph * FUSED_GROUPS + wave) + 1]);
+        if (n_lines > 0) {
+            uint4 a = prog4[2 * first], b = prog4[2 * first + 1];
+            for (int ln = 0; ln < n_lines; ++ln) {
+                uint4 na = a, nb = b;
+                if (ln + 1 < n_lines) {  // next line: scalar loads that land while this line's LDS reads fly
+                    na = prog4[2 * (first + ln) + 2];
+                    nb = prog4[2 * (first + ln) + 3];
+                }
+                const uint32_t h = a.x;
+                const uint32_t kind = h >> 28;
+                const uint32_t cnt = (h >> 15) & 7u;
+                const uint32_t w[7] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (kind == LINE_MACS) {
+                    fused_mac_dispatch<T, false>(h, w, my, acc, ctab);
+                } else if (kind == LINE_MACS_GEN) {
+                    fused_mac_dispatch<T, true>(h, w, my, acc, ctab);
+                } else if (kind == LINE_MISC) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                        if (uint32_t(k) < cnt) fused_misc<T>(w[k], my);
+                }
+                a = na;
+                b = nb;
+            }
         }
-        fused_exec<T>(a.x, my, acc, p);
-        fused_exec<T>(a.y, my, acc, p);
-        fused_exec<T>(a.z, my, acc, p);
-        fused_exec<T>(a.w, my, acc, p);
-        fused_exec<T>(b.x, my, acc, p);
-        fused_exec<T>(b.y, my, acc, p);
-        fused_exec<T>(b.z, my, acc, p);
-        fused_exec<T>(b.w, my, acc, p);
-        a = na;
-        b = nb;
+        __syncthreads();  // the next step reads what every wave wrote
     }
-    __syncthreads();
 
     // ---- write the root result rows back, coalesced ----
-    {
+    if (p.out_len > 0) {
         const int len = p.out_len;
         T* dst = p.out_ptr + item0 * p.out_stride;
         const int total = nitems * len;
@@ -325,7 +381,7 @@ struct DenseArgs {
     const T* right;
     T* out;
     int64_t left_stride, right_stride, out_stride;
-    const uint32_t* left_map;   // per loaded component: row offset | bitmask << 16
+    const uint32_t* left_map;   // per loaded component: row offset | bitmask << 16 | negate << 31
     const uint32_t* right_map;
     int left_count, right_count;
     int left_full, right_full;  // 1: every blade is loaded, no zero fill needed
@@ -502,13 +558,15 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
             const uint32_t m = p.left_map[j];
             T v = lrow[m & 0xffffu];
             if (p.canon_left) v = zero + v;
-            as[dense_lds_pos(int(m >> 16))] = v;
+            if (m >> 31) v = -v;  // a folded Negation / Reverse / GradeInvolution of this grade
+            as[dense_lds_pos(int((m >> 16) & 0x7fffu))] = v;
         }
         for (int j = tid; j < p.right_count; j += THREADS) {
             const uint32_t m = p.right_map[j];
             T v = rrow[m & 0xffffu];
             if (p.canon_right) v = zero + v;
-            bs[dense_lds_pos(int(m >> 16))] = v;
+            if (m >> 31) v = -v;
+            bs[dense_lds_pos(int((m >> 16) & 0x7fffu))] = v;
         }
     }
     __syncthreads();

@@ -197,11 +197,45 @@ struct Lowering {
         }
     }
 
-    BufRef operand(int id, int* canon) {
+    // Which buffer a Product reads for operand `id`.  Exact rewrites (off with NO_FUSION):
+    //  - a bound input holding every wanted grade is read in place (canon: 0.0 + x);
+    //  - a chain of sign-only arms (Negation / Reverse / GradeInvolution / GradeProjection) over
+    //    such an input is not materialised either: the grades it negates are returned in *flip
+    //    and folded into the comp-mul coefficients -- ((-l) * r) * c == (l * r) * (-c) bit for bit.
+    BufRef operand(int id, int* canon, uint64_t* flip) {
         *canon = 0;
-        if (!(plan.flags & GAAST_FLAG_NO_FUSION) && direct_input_ok(id)) {
-            *canon = 1;
-            return BufRef{BufKind::INPUT, node(id).input_slot};
+        *flip = 0;
+        if (!(plan.flags & GAAST_FLAG_NO_FUSION) && cache[size_t(id)] < 0) {
+            uint64_t f = 0;
+            int cur = id;
+            bool ok_chain = true;
+            while (node(cur).opcode != GAAST_OP_INPUT) {
+                const gaast_node_desc& nd = node(cur);
+                const uint64_t gs = nd.minimal_grade_mask;
+                const bool sign_only = nd.opcode == GAAST_OP_NEG || nd.opcode == GAAST_OP_REVERSE ||
+                                       nd.opcode == GAAST_OP_GINVOL || nd.opcode == GAAST_OP_PROJ;
+                // the child must fill exactly the grades this node's buffer would have (Q2 otherwise)
+                if (!sign_only || node(nd.child0).minimal_grade_mask != gs || gs == 0) {
+                    ok_chain = false;
+                    break;
+                }
+                if (nd.opcode == GAAST_OP_REVERSE && (gs & 1ULL) && (plan.flags & GAAST_FLAG_DEBUG_OVERFLOW)) {
+                    ok_chain = false;  // let the materialising path report the panic
+                    break;
+                }
+                for (int k = 0; k < 64; ++k) {
+                    if (!((gs >> k) & 1ULL)) continue;
+                    const bool neg = nd.opcode == GAAST_OP_NEG || (nd.opcode == GAAST_OP_REVERSE && (k % 4 == 2 || k % 4 == 3)) ||
+                                     (nd.opcode == GAAST_OP_GINVOL && (k & 1));
+                    if (neg) f ^= 1ULL << k;
+                }
+                cur = nd.child0;
+            }
+            if (ok_chain && direct_input_ok(cur)) {
+                *canon = 1;
+                *flip = f;
+                return BufRef{BufKind::INPUT, node(cur).input_slot};
+            }
         }
         return store_in_cache(id);  // eval.rs:67-68
     }
@@ -224,9 +258,10 @@ struct Lowering {
     void lower_product(BufRef res, int id) {  // eval.rs:61-86
         const gaast_node_desc& nd = node(id);
         int canon_l = 0, canon_r = 0;
-        BufRef l = operand(nd.child0, &canon_l);
+        uint64_t flip_l = 0, flip_r = 0;
+        BufRef l = operand(nd.child0, &canon_l, &flip_l);
         if (!ok()) return;
-        BufRef r = operand(nd.child1, &canon_r);
+        BufRef r = operand(nd.child1, &canon_r, &flip_r);
         if (!ok()) return;
         if (key(l) == key(res) || key(r) == key(res)) {
             fail(GAAST_ERR_MISSING_GRADE, "product operand aliases its own result buffer");
@@ -259,16 +294,18 @@ struct Lowering {
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
             const int n = d.vec_space_dim;
-            auto build_map = [&](const Layout& lay, uint64_t want, std::vector<uint32_t>& map, int* full) {
+            // entry: row offset | blade bitmask << 16 | (negate while staging) << 31
+            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, std::vector<uint32_t>& map, int* full) {
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
+                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i)
-                        map.push_back(uint32_t(lay.offset(k) + i) | (bt.blade_of[size_t(k)][i] << 16));
+                        map.push_back(uint32_t(lay.offset(k) + i) | (bt.blade_of[size_t(k)][i] << 16) | sgn);
                 }
                 *full = map.size() == (size_t(1) << n);
             };
-            build_map(ll, lmin & ll.mask, s.u32_a, &s.left_full);
-            build_map(lrr, rmin & lrr.mask, s.u32_b, &s.right_full);
+            build_map(ll, lmin & ll.mask, flip_l, s.u32_a, &s.left_full);
+            build_map(lrr, rmin & lrr.mask, flip_r, s.u32_b, &s.right_full);
             s.i32_a.assign(size_t(1) << n, -1);
             for (uint32_t m = 0; m < (1u << n); ++m) {
                 const int g = __builtin_popcount(m);
@@ -352,7 +389,8 @@ struct Lowering {
             const uint32_t lo = uint32_t(ll.offset(int(m.left_grade)) + m.left_index);
             const uint32_t ro = uint32_t(lrr.offset(int(m.right_grade)) + m.right_index);
             s.u32_c[pos] = lo | (ro << 16);
-            s.coeff[pos] = m.coeff;
+            const bool neg = (((flip_l >> m.left_grade) ^ (flip_r >> m.right_grade)) & 1ULL) != 0;
+            s.coeff[pos] = neg ? -m.coeff : m.coeff;
         }
         touch(res);
     }
@@ -417,61 +455,115 @@ bool try_fuse(Plan& plan) {
         return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)]
                : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)] : plan.out_layout;
     };
-    std::vector<uint32_t>& prog = f.u32_a;
-    auto op = [](uint32_t code, uint32_t lo, uint32_t mid = 0, uint32_t c = 0) {
-        return (code << 28) | (c << 24) | (mid << 12) | lo;
-    };
+    // One phase per step; inside a phase the independent result rows (and element-wise ops) are
+    // dealt to the workgroup's waves, least-loaded first.  Any split is exact: rows of one
+    // Product never read what another row of the same Product writes.
+    constexpr int G = uop::GROUPS;
+    std::vector<uint32_t>& prog = f.u32_a;        // 8-word lines, see kernels.hip.hpp
+    std::vector<uint32_t>& phase_tab = f.u32_b;   // per (phase, wave): first line, line count
     std::vector<double>& general = f.coeff;
     uint64_t entries = 0;
+    auto mop = [](uint32_t code, uint32_t lo, uint32_t mid = 0) { return (code << 28) | (mid << 12) | lo; };
     for (const Step& s : plan.steps) {
+        std::vector<std::vector<uint32_t>> glines(G);  // lines of each wave, this phase
+        std::vector<uint64_t> load(G, 0);
+        auto least = [&]() {
+            int g = 0;
+            for (int i = 1; i < G; ++i)
+                if (load[size_t(i)] < load[size_t(g)]) g = i;
+            return g;
+        };
+        auto push_misc = [&](const std::vector<uint32_t>& ops) {  // chunks of 7 ops, dealt round
+            for (size_t i = 0; i < ops.size(); i += 7) {
+                const size_t cnt = std::min<size_t>(7, ops.size() - i);
+                const int g = least();
+                glines[size_t(g)].push_back((uint32_t(uop::LINE_MISC) << 28) | (uint32_t(cnt) << 15));
+                for (size_t k = 0; k < 7; ++k) glines[size_t(g)].push_back(k < cnt ? ops[i + k] : 0u);
+                load[size_t(g)] += cnt;
+            }
+        };
         const uint32_t rb = uint32_t(base_of(s.res));
+        std::vector<uint32_t> misc;
         switch (s.kind) {
-        case Step::ZERO:
-            if (layout_of(s.res).row_len) prog.push_back(op(uop::ZERO, rb, uint32_t(layout_of(s.res).row_len)));
+        case Step::ZERO: {
+            const uint32_t len = uint32_t(layout_of(s.res).row_len);
+            for (uint32_t o = 0; o < len; o += 16) misc.push_back(mop(uop::ZERO, rb + o, std::min<uint32_t>(16, len - o)));
+            push_misc(misc);
             break;
+        }
         case Step::AXPY:
-            for (uint32_t m : s.u32_a) prog.push_back(op(uop::ADD, rb + (m & 0xffffu), uint32_t(base_of(s.a)) + (m >> 16)));
+            for (uint32_t m : s.u32_a) misc.push_back(mop(uop::ADD, rb + (m & 0xffffu), uint32_t(base_of(s.a)) + (m >> 16)));
+            push_misc(misc);
             break;
         case Step::FLIP:
-            for (uint32_t o : s.u32_a) prog.push_back(op(uop::NEG, rb + o));
+            for (uint32_t o : s.u32_a) misc.push_back(mop(uop::NEG, rb + o));
+            push_misc(misc);
             break;
         case Step::SUNARY:
-            prog.push_back(op(s.sunary_op == 0 ? uop::INV : uop::SQRT, rb + uint32_t(s.sunary_off)));
+            misc.push_back(mop(s.sunary_op == 0 ? uop::INV : uop::SQRT, rb + uint32_t(s.sunary_off)));
+            push_misc(misc);
             break;
         case Step::PRODUCT_CSR: {
             const uint32_t lb = uint32_t(base_of(s.a, s.canon_a)), rrb = uint32_t(base_of(s.b, s.canon_b));
             for (size_t row = 0; row + 1 < s.u32_a.size(); ++row) {
                 const uint32_t dst = rb + s.u32_b[row];
-                prog.push_back(op(uop::ROW, dst, s.beta ? 0u : 1u));
-                for (uint32_t e = s.u32_a[row]; e < s.u32_a[row + 1]; ++e) {
-                    const double c = s.coeff[e];
-                    uint32_t ci;
-                    if (c == 1.0) {
-                        ci = 0;
-                    } else if (c == -1.0) {
-                        ci = 1;
-                    } else {
-                        size_t g = 0;
-                        for (; g < general.size(); ++g)
-                            if (std::memcmp(&general[g], &c, sizeof(double)) == 0) break;
-                        if (g == general.size()) {
-                            if (general.size() == size_t(uop::MAX_GENERAL_COEFFS)) return false;
-                            general.push_back(c);
+                const uint32_t e0 = s.u32_a[row], e1 = s.u32_a[row + 1];
+                const int g = least();
+                std::vector<uint32_t>& out = glines[size_t(g)];
+                load[size_t(g)] += (e1 - e0) + 2;
+                uint32_t e = e0;
+                do {  // a row with no entries still stores its (fresh) 0.0
+                    const uint32_t cnt = std::min<uint32_t>(7, e1 - e);
+                    uint32_t hdr = dst | (cnt << 15);
+                    if (e == e0) hdr |= (1u << 12) | (s.beta ? 0u : (1u << 13));
+                    if (e + cnt == e1) hdr |= 1u << 14;
+                    const size_t hdr_pos = out.size();
+                    out.push_back(hdr);
+                    bool any_general = false;
+                    for (uint32_t k = 0; k < 7; ++k) {
+                        if (k >= cnt) {
+                            out.push_back(0u);
+                            continue;
                         }
-                        ci = uint32_t(g) + 2;
+                        const double c = s.coeff[e + k];
+                        uint32_t ci;
+                        if (c == 1.0) {
+                            ci = 0;
+                        } else if (c == -1.0) {
+                            ci = 1;
+                        } else {
+                            size_t gi = 0;
+                            for (; gi < general.size(); ++gi)
+                                if (std::memcmp(&general[gi], &c, sizeof(double)) == 0) break;
+                            if (gi == general.size()) {
+                                if (general.size() == size_t(uop::MAX_GENERAL_COEFFS)) return false;
+                                general.push_back(c);
+                            }
+                            ci = uint32_t(gi) + 2;
+                            any_general = true;
+                        }
+                        out.push_back((ci << 24) | ((rrb + (s.u32_c[e + k] >> 16)) << 12) | (lb + (s.u32_c[e + k] & 0xffffu)));
+                        ++entries;
                     }
-                    prog.push_back(op(uop::MAC, lb + (s.u32_c[e] & 0xffffu), rrb + (s.u32_c[e] >> 16), ci));
-                    ++entries;
-                }
-                prog.push_back(op(uop::ST, dst));
+                    out[hdr_pos] |= uint32_t(any_general ? uop::LINE_MACS_GEN : uop::LINE_MACS) << 28;
+                    e += cnt;
+                } while (e < e1);
             }
             break;
         }
         default: return false;
         }
+        for (int g = 0; g < G; ++g) {
+            phase_tab.push_back(uint32_t(prog.size() / 8));
+            phase_tab.push_back(uint32_t(glines[size_t(g)].size() / 8));
+            prog.insert(prog.end(), glines[size_t(g)].begin(), glines[size_t(g)].end());
+        }
     }
-    if (prog.size() > (1u << 16)) return false;
-    while (prog.size() % 8 != 0 || prog.empty()) prog.push_back(op(uop::NOP, 0));
+    if (prog.size() > (1u << 18)) return false;
+    if (prog.empty()) {
+        prog.push_back(uint32_t(uop::LINE_NOP) << 28);
+        for (int k = 0; k < 7; ++k) prog.push_back(0u);
+    }
     f.fused_slab = slab;
     f.fused_out_base = out_base;
     f.n_entries = entries;

@@ -86,9 +86,10 @@ void build_plan(const gaast_program_desc& desc, Plan& plan);
 
 // Micro-op encoding shared by the plan builder and k_ast_fused (see kernels.hip.hpp).
 namespace uop {
-enum : uint32_t { MAC = 0, ROW = 1, ST = 2, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7, NOP = 8 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7 };
 constexpr int MAX_GENERAL_COEFFS = 6;
 constexpr int MAX_INPUTS = 8;
+constexpr int GROUPS = 4;  // waves per workgroup of k_ast_fused (FUSED_GROUPS)
 }  // namespace uop
 
 }  // namespace gaast

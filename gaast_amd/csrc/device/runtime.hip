@@ -222,7 +222,8 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     FusedArgs<T> p;
     std::memset(&p, 0, sizeof(p));
     p.prog = static_cast<const uint32_t*>(s.d_a);
-    p.n_words = int(s.u32_a.size());
+    p.phase_tab = static_cast<const uint32_t*>(s.d_b);
+    p.n_phases = int(s.u32_b.size() / (2 * FUSED_GROUPS));
     for (size_t i = 0; i < s.coeff_host.size() && i < 6; ++i) p.coeff[i] = T(s.coeff_host[i]);
     p.slab = s.fused_slab;
     p.n_in = int(s.fused_inputs.size());
@@ -239,8 +240,8 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     p.out_len = int(plan.out_layout.row_len);
     p.out_base = s.fused_out_base;
     p.batch = batch;
-    const size_t lds = size_t(p.slab) * sizeof(T) * FUSED_THREADS;
-    const int64_t blocks = (batch + FUSED_THREADS - 1) / FUSED_THREADS;
+    const size_t lds = (size_t(p.slab) * FUSED_ITEMS + 8) * sizeof(T);
+    const int64_t blocks = (batch + FUSED_ITEMS - 1) / FUSED_ITEMS;
     hipLaunchKernelGGL(k_ast_fused<T>, dim3(unsigned(blocks)), dim3(FUSED_THREADS), lds, g_stream, p);
     HIP_TRY(hipGetLastError());
     return GAAST_OK;
