@@ -151,22 +151,23 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 //              begin: acc = fresh ? 0.0 : slab[dst];   end: slab[dst] = acc
 //              MAC slot: l[11:0] r[23:12] c[26:24]:  acc = acc + (slab[l] * slab[r]) * coeff(c)
 //              with coeff(0) = +1, coeff(1) = -1, c >= 2 -> general table[c-2].
-//              LINE_MACS holds only c in {0,1} and applies the sign by flipping the product's
-//              sign bit (identical to multiplying by +-1.0); LINE_MACS_GEN multiplies by the
-//              coefficient like eval.rs:82 does.  The body is straight-line per count: all
-//              operands of a line are fetched before the first multiply.
+//              LINE_MACS: 7 sign-only slots (coefficients +-1, the sign applied by flipping the
+//              product's sign bit = multiplying by +-1.0), straight-line, all 14 operands fetched
+//              before the first multiply; LINE_MACS_CNT: same slots, counted, for rows that
+//              accumulate into an existing value; LINE_MACS_GEN: counted, multiplies by the
+//              coefficient like eval.rs:82.
 //   LINE_MISC  count[17:15]; words 1..count = element-wise micro-ops, [31:28] opcode:
 //              ADD dst[11:0] src[23:12]   slab[dst] = slab[dst] + slab[src]     (graded.rs:74)
 //              NEG dst                    slab[dst] = -slab[dst]                 (graded.rs:63)
 //              ZERO dst count[23:12]      slab[dst..dst+count) = 0.0             (graded.rs:195-201)
 //              INV / SQRT dst             eval.rs:106-109
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, LINE_MACS_CNT = 4 };
 enum : uint32_t { UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5, UOP_INV = 6, UOP_SQRT = 7 };
 
 constexpr int FUSED_MAX_INPUTS = 8;
 constexpr int FUSED_ITEMS = 64;    // items per workgroup: lane <-> item
-constexpr int FUSED_GROUPS = 4;    // waves per workgroup: the independent result rows of a step are
+constexpr int FUSED_GROUPS = 8;    // waves per workgroup: the independent result rows of a step are
                                    // dealt to the waves, all working on the same 64 slabs
 constexpr int FUSED_THREADS = FUSED_ITEMS * FUSED_GROUPS;
 
@@ -177,6 +178,7 @@ struct FusedArgs {
     int n_phases;
     T coeff[6];             // general coefficients (c >= 2)
     int slab;               // S: elements per item, odd
+    int zero_slot;          // slab offset of an element holding +0.0 (target of unused MAC slots)
     int n_in;
     const T* in_ptr[FUSED_MAX_INPUTS];
     int64_t in_stride[FUSED_MAX_INPUTS];
@@ -187,6 +189,7 @@ struct FusedArgs {
     int64_t out_stride;
     int out_len, out_base;
     int64_t batch;
+    int debug_skip;         // diagnostics only (GAAST_DEBUG_FUSED_SKIP): 1 = no compute, 2 = no staging, 4 = no write-back
 };
 
 template <typename T>
@@ -214,54 +217,75 @@ __device__ __forceinline__ void fused_misc(uint32_t w, T* __restrict__ my) {
     }
 }
 
-__device__ __forceinline__ float flip_sign(float t, uint32_t s) {
-    return __uint_as_float(__float_as_uint(t) ^ (s << 31));
+// Sign-only MAC slot (LINE_MACS / LINE_MACS_CNT): byte offsets, pre-scaled on the host:
+//   [14:0] left byte offset   [29:15] right byte offset   [31] negate the product
+// General slot (LINE_MACS_GEN): [11:0] left element  [23:12] right element  [26:24] coefficient id
+__device__ __forceinline__ float flip_sign_bit(float t, uint32_t w) {
+    return __uint_as_float(__float_as_uint(t) ^ (w & 0x80000000u));
 }
-__device__ __forceinline__ double flip_sign(double t, uint32_t s) {
-    return __hiloint2double(__double2hiint(t) ^ int(s << 31), __double2loint(t));
+__device__ __forceinline__ double flip_sign_bit(double t, uint32_t w) {
+    return __hiloint2double(__double2hiint(t) ^ int(w & 0x80000000u), __double2loint(t));
 }
 
-template <typename T, int CNT, bool GENERAL>
-__device__ __forceinline__ void fused_mac_line(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
-                                               const T* __restrict__ ctab) {
-    T l[CNT], r[CNT], cf[CNT];
+template <typename T>
+__device__ __forceinline__ T lds_at(const T* my, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(my) + byte_off);
+}
+
+// A line of CNT sign-only slots, straight-line: 2*CNT LDS reads in flight, then the sum.
+template <typename T, int CNT>
+__device__ __forceinline__ void fused_mac_n(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc) {
+    T l[CNT], r[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
-        l[k] = my[w[k] & 0xfffu];
-        r[k] = my[(w[k] >> 12) & 0xfffu];
-        if (GENERAL) cf[k] = ctab[(w[k] >> 24) & 7u];
+        l[k] = lds_at<T>(my, w[k] & 0x7fffu);
+        r[k] = lds_at<T>(my, (w[k] >> 15) & 0x7fffu);
     }
     T* d = my + (h & 0xfffu);
     if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) {
-        const T t = l[k] * r[k];
-        if (GENERAL)
-            acc = acc + t * cf[k];                          // eval.rs:82
-        else
-            acc = acc + flip_sign(t, (w[k] >> 24) & 1u);     // (l*r)*(+-1.0), exact
-    }
+    for (int k = 0; k < CNT; ++k) acc = acc + flip_sign_bit(l[k] * r[k], w[k]);  // (l*r)*(+-1.0), exact
     if (h & (1u << 14)) *d = acc;
 }
 
-template <typename T, bool GENERAL>
-__device__ __forceinline__ void fused_mac_dispatch(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
-                                                   const T* __restrict__ ctab) {
-    switch ((h >> 15) & 7u) {
-    case 0: {  // an empty row: only begin / end
+template <typename T>
+__device__ __forceinline__ void fused_mac_full(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc) {
+    switch ((h >> 15) & 7u) {  // wave-uniform: one jump per line, then straight-line code
+    case 7: fused_mac_n<T, 7>(h, w, my, acc); break;
+    case 6: fused_mac_n<T, 6>(h, w, my, acc); break;
+    case 5: fused_mac_n<T, 5>(h, w, my, acc); break;
+    case 4: fused_mac_n<T, 4>(h, w, my, acc); break;
+    case 3: fused_mac_n<T, 3>(h, w, my, acc); break;
+    case 2: fused_mac_n<T, 2>(h, w, my, acc); break;
+    case 1: fused_mac_n<T, 1>(h, w, my, acc); break;
+    default: {
         T* d = my + (h & 0xfffu);
         if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
         if (h & (1u << 14)) *d = acc;
-        break;
     }
-    case 1: fused_mac_line<T, 1, GENERAL>(h, w, my, acc, ctab); break;
-    case 2: fused_mac_line<T, 2, GENERAL>(h, w, my, acc, ctab); break;
-    case 3: fused_mac_line<T, 3, GENERAL>(h, w, my, acc, ctab); break;
-    case 4: fused_mac_line<T, 4, GENERAL>(h, w, my, acc, ctab); break;
-    case 5: fused_mac_line<T, 5, GENERAL>(h, w, my, acc, ctab); break;
-    case 6: fused_mac_line<T, 6, GENERAL>(h, w, my, acc, ctab); break;
-    default: fused_mac_line<T, 7, GENERAL>(h, w, my, acc, ctab); break;
     }
+}
+
+// Counted variants (rows accumulating into an existing value, general coefficients): rare.
+template <typename T, bool GENERAL>
+__device__ __forceinline__ void fused_mac_counted(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
+                                                  const T* __restrict__ ctab) {
+    const uint32_t cnt = (h >> 15) & 7u;
+    T* d = my + (h & 0xfffu);
+    if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        if (uint32_t(k) < cnt) {
+            if (GENERAL) {
+                const T t = my[w[k] & 0xfffu] * my[(w[k] >> 12) & 0xfffu];
+                acc = acc + t * ctab[(w[k] >> 24) & 7u];  // eval.rs:82
+            } else {
+                const T t = lds_at<T>(my, w[k] & 0x7fffu) * lds_at<T>(my, (w[k] >> 15) & 0x7fffu);
+                acc = acc + flip_sign_bit(t, w[k]);
+            }
+        }
+    }
+    if (h & (1u << 14)) *d = acc;
 }
 
 template <typename T>
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     const int nitems = int(p.batch - item0 < FUSED_ITEMS ? p.batch - item0 : FUSED_ITEMS);
 
     // ---- stage the inputs: element e of the block's contiguous row range -> (item, comp) ----
-    for (int s = 0; s < p.n_in; ++s) {
+    for (int s = 0; s < ((p.debug_skip & 2) ? 0 : p.n_in); ++s) {
         const int len = p.in_len[s];
         if (len <= 0) continue;
         const T* src = p.in_ptr[s] + item0 * p.in_stride[s];
@@ -295,6 +319,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     }
     // coefficient table behind the slabs: [+1, -1, general...]
     T* ctab = smem + FUSED_ITEMS * S;
+    if (tid < FUSED_ITEMS) smem[tid * S + p.zero_slot] = T(0);  // the item's zero element
     if (tid < 8) ctab[tid] = tid == 0 ? T(1) : tid == 1 ? T(-1) : p.coeff[tid - 2 < 6 ? tid - 2 : 0];
     __syncthreads();
 
@@ -302,27 +327,31 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     T* my = smem + (tid & 63) * S;
     T acc = T(0);
+    // Program lines come through the scalar cache (the stream is wave-uniform), one line ahead;
+    // headers and slots are decoded on the scalar unit: byte offsets are pre-scaled on the host
+    // so that a slot costs one s_and, one s_bfe and the sign mask.
     const uint4* prog4 = reinterpret_cast<const uint4*>(p.prog);
-    for (int ph = 0; ph < p.n_phases; ++ph) {
+    for (int ph = 0; ph < ((p.debug_skip & 1) ? 0 : p.n_phases); ++ph) {
         const uint32_t first = p.phase_tab[2 * (ph * FUSED_GROUPS + wave)];
         const int n_lines = int(p.phase_tab[2 * (ph * FUSED_GROUPS + wave) + 1]);
         if (n_lines > 0) {
-            uint4 a = prog4[2 * first], b = prog4[2 * first + 1];
+            const uint4* lp = prog4 + 2 * first;
+            uint4 a = lp[0], b = lp[1];
             for (int ln = 0; ln < n_lines; ++ln) {
                 uint4 na = a, nb = b;
-                if (ln + 1 < n_lines) {  // next line: scalar loads that land while this line's LDS reads fly
-                    na = prog4[2 * (first + ln) + 2];
-                    nb = prog4[2 * (first + ln) + 3];
+                if (ln + 1 < n_lines) {
+                    na = lp[2 * ln + 2];
+                    nb = lp[2 * ln + 3];
                 }
                 const uint32_t h = a.x;
                 const uint32_t kind = h >> 28;
-                const uint32_t cnt = (h >> 15) & 7u;
                 const uint32_t w[7] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 if (kind == LINE_MACS) {
-                    fused_mac_dispatch<T, false>(h, w, my, acc, ctab);
+                    fused_mac_full<T>(h, w, my, acc);
                 } else if (kind == LINE_MACS_GEN) {
-                    fused_mac_dispatch<T, true>(h, w, my, acc, ctab);
+                    fused_mac_counted<T, true>(h, w, my, acc, ctab);
                 } else if (kind == LINE_MISC) {
+                    const uint32_t cnt = (h >> 15) & 7u;
 #pragma unroll
                     for (int k = 0; k < 7; ++k)
                         if (uint32_t(k) < cnt) fused_misc<T>(w[k], my);
@@ -335,7 +364,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     }
 
     // ---- write the root result rows back, coalesced ----
-    if (p.out_len > 0) {
+    if (p.out_len > 0 && !(p.debug_skip & 4)) {
         const int len = p.out_len;
         T* dst = p.out_ptr + item0 * p.out_stride;
         const int total = nitems * len;

@@ -444,8 +444,9 @@ bool try_fuse(Plan& plan) {
     const int out_base = cursor;
     cursor += int(plan.out_layout.row_len);
     if (plan.out_layout.row_len == 0) return false;
+    const int zero_slot = cursor++;  // one element per item holding +0.0: target of unused MAC slots
     int slab = cursor | 1;  // odd: 64 lanes at one slab offset hit 64 different banks
-    if (slab > 4095 || size_t(slab) * elem * 64 > 48 * 1024) return false;
+    if (slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024) return false;
     auto base_of = [&](BufRef r, int canon = 0) {
         return r.kind == BufKind::NODE    ? node_base[size_t(r.idx)]
                : r.kind == BufKind::INPUT ? (canon ? in_base_canon : in_base)[size_t(r.idx)]
@@ -511,41 +512,48 @@ bool try_fuse(Plan& plan) {
                 const int g = least();
                 std::vector<uint32_t>& out = glines[size_t(g)];
                 load[size_t(g)] += (e1 - e0) + 2;
+                // classify the row: sign-only fresh rows get padded full lines
+                bool row_general = false;
+                for (uint32_t e = e0; e < e1; ++e) row_general |= (s.coeff[e] != 1.0 && s.coeff[e] != -1.0);
+                const bool full_lines = !row_general;
+                const uint32_t esz = uint32_t(elem);
                 uint32_t e = e0;
                 do {  // a row with no entries still stores its (fresh) 0.0
                     const uint32_t cnt = std::min<uint32_t>(7, e1 - e);
                     uint32_t hdr = dst | (cnt << 15);
                     if (e == e0) hdr |= (1u << 12) | (s.beta ? 0u : (1u << 13));
                     if (e + cnt == e1) hdr |= 1u << 14;
-                    const size_t hdr_pos = out.size();
+                    hdr |= uint32_t(full_lines ? uop::LINE_MACS : row_general ? uop::LINE_MACS_GEN : uop::LINE_MACS_CNT) << 28;
                     out.push_back(hdr);
-                    bool any_general = false;
                     for (uint32_t k = 0; k < 7; ++k) {
                         if (k >= cnt) {
                             out.push_back(0u);
                             continue;
                         }
                         const double c = s.coeff[e + k];
-                        uint32_t ci;
-                        if (c == 1.0) {
-                            ci = 0;
-                        } else if (c == -1.0) {
-                            ci = 1;
+                        const uint32_t lo = lb + (s.u32_c[e + k] & 0xffffu), ro = rrb + (s.u32_c[e + k] >> 16);
+                        if (!row_general) {
+                            out.push_back((lo * esz) | ((ro * esz) << 15) | (c == -1.0 ? 0x80000000u : 0u));
                         } else {
-                            size_t gi = 0;
-                            for (; gi < general.size(); ++gi)
-                                if (std::memcmp(&general[gi], &c, sizeof(double)) == 0) break;
-                            if (gi == general.size()) {
-                                if (general.size() == size_t(uop::MAX_GENERAL_COEFFS)) return false;
-                                general.push_back(c);
+                            uint32_t ci;
+                            if (c == 1.0) {
+                                ci = 0;
+                            } else if (c == -1.0) {
+                                ci = 1;
+                            } else {
+                                size_t gi = 0;
+                                for (; gi < general.size(); ++gi)
+                                    if (std::memcmp(&general[gi], &c, sizeof(double)) == 0) break;
+                                if (gi == general.size()) {
+                                    if (general.size() == size_t(uop::MAX_GENERAL_COEFFS)) return false;
+                                    general.push_back(c);
+                                }
+                                ci = uint32_t(gi) + 2;
                             }
-                            ci = uint32_t(gi) + 2;
-                            any_general = true;
+                            out.push_back((ci << 24) | (ro << 12) | lo);
                         }
-                        out.push_back((ci << 24) | ((rrb + (s.u32_c[e + k] >> 16)) << 12) | (lb + (s.u32_c[e + k] & 0xffffu)));
                         ++entries;
                     }
-                    out[hdr_pos] |= uint32_t(any_general ? uop::LINE_MACS_GEN : uop::LINE_MACS) << 28;
                     e += cnt;
                 } while (e < e1);
             }
@@ -565,6 +573,7 @@ bool try_fuse(Plan& plan) {
         for (int k = 0; k < 7; ++k) prog.push_back(0u);
     }
     f.fused_slab = slab;
+    f.fused_zero_slot = zero_slot;
     f.fused_out_base = out_base;
     f.n_entries = entries;
     f.name = "ast_fused[" + std::to_string(plan.steps.size()) + " arms, " + std::to_string(entries) +

@@ -57,7 +57,7 @@ struct Step {
         int slot, base, canon;
     };
     std::vector<FusedInput> fused_inputs;
-    int fused_slab = 0, fused_out_base = 0;
+    int fused_slab = 0, fused_out_base = 0, fused_zero_slot = 0;
     // device copies
     void* d_a = nullptr;
     void* d_b = nullptr;
@@ -86,10 +86,10 @@ void build_plan(const gaast_program_desc& desc, Plan& plan);
 
 // Micro-op encoding shared by the plan builder and k_ast_fused (see kernels.hip.hpp).
 namespace uop {
-enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, LINE_MACS_CNT = 4, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7 };
 constexpr int MAX_GENERAL_COEFFS = 6;
 constexpr int MAX_INPUTS = 8;
-constexpr int GROUPS = 4;  // waves per workgroup of k_ast_fused (FUSED_GROUPS)
+constexpr int GROUPS = 8;  // waves per workgroup of k_ast_fused (FUSED_GROUPS)
 }  // namespace uop
 
 }  // namespace gaast

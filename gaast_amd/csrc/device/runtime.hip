@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -226,6 +227,7 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     p.n_phases = int(s.u32_b.size() / (2 * FUSED_GROUPS));
     for (size_t i = 0; i < s.coeff_host.size() && i < 6; ++i) p.coeff[i] = T(s.coeff_host[i]);
     p.slab = s.fused_slab;
+    p.zero_slot = s.fused_zero_slot;
     p.n_in = int(s.fused_inputs.size());
     for (int i = 0; i < p.n_in; ++i) {
         const Step::FusedInput& fi = s.fused_inputs[size_t(i)];
@@ -240,6 +242,8 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     p.out_len = int(plan.out_layout.row_len);
     p.out_base = s.fused_out_base;
     p.batch = batch;
+    static const int dbg = std::getenv("GAAST_DEBUG_FUSED_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_FUSED_SKIP")) : 0;
+    p.debug_skip = dbg;
     const size_t lds = (size_t(p.slab) * FUSED_ITEMS + 8) * sizeof(T);
     const int64_t blocks = (batch + FUSED_ITEMS - 1) / FUSED_ITEMS;
     hipLaunchKernelGGL(k_ast_fused<T>, dim3(unsigned(blocks)), dim3(FUSED_THREADS), lds, g_stream, p);
