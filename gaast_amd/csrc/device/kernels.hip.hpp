@@ -645,4 +645,162 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Product arm, dense geometric product on the matrix cores (f32, n >= 10).
+//
+// With lo = 5 bits (blocks of 32) the per-item product is, for every A block a_hi,
+//     C[c_lo][c_hi] += sum_k  M[c_lo][k] * Bs[k][c_hi],      k = b_lo,
+//     M[i][k]  = s_lo(i^k, k) (-1)^(|a_hi| |k|) A[a_hi][i ^ k]             (32 x 32, built on the fly)
+//     Bs[k][j] = s_blk(a_hi, b_hi(j)) B[b_hi(j)][k],   b_hi(j) = a_hi ^ c_hi(j)  (32 x 32 columns)
+// i.e. a genuine 32x32x32 GEMM tile per (a_hi, 32 result columns): 16 v_mfma_f32_32x32x2_f32.
+// The MFMA A operand of lane l is M[i = l&31][k = 2s + (l>>5)]: one ds_read_b32 of the A block
+// at a lane-permuted position (conflict-free: the 32 lanes of a half-wave read a permutation
+// of the block's 32 dwords) and one sign flip with a lane-constant mask.  The B operand of
+// lane l is Bs[k = 2s + (l>>5)][j = l&31]: the 16 components of its own B block with index
+// parity (l>>5), stored de-interleaved so that they are 64 contiguous bytes (4 ds_read_b128,
+// quads rotated by (x>>1)&7 per block x: 16 lanes reading the same logical quad of 16 blocks
+// hit 16 different bank quads), times the block sign.  f32 MFMA accumulates like a k-ordered
+// fmaf chain, at the vector FMA rate, without occupying the vector ALUs.
+// Requires the low FIVE basis vectors to square to +1.
+// ------------------------------------------------------------------------------------------
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ constexpr int lo5_reorder_parity(int a, int b) {
+    int par = 0;
+    for (int p = 1; p < 5; ++p)
+        if ((a >> p) & 1)
+            for (int q = 0; q < p; ++q) par ^= (b >> q) & 1;
+    return par;
+}
+
+// LDS position of blade m inside the B image: block x = m >> 5; inside it the components are
+// de-interleaved by the parity of k = m & 31 (even k first), 8 quads rotated by (x >> 1) & 7.
+__device__ __forceinline__ int mfma_b_pos(int m) {
+    const int x = m >> 5, k = m & 31;
+    const int lq = ((k & 1) << 2) | (k >> 3);   // logical quad: parity * 4 + (k/2)/4
+    return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
+}
+
+template <bool DEGENERATE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int n = p.n;
+    const int N = 1 << n;
+    const int hbits = n - 5;
+    const int H = 1 << hbits;                     // number of 32-blocks
+    const int WPI = H >> 5;                       // waves per item (32 result columns each)
+    const int IPB = (THREADS >> 6) / WPI;         // items per block (>= 1)
+    const int item_stride = 2 * N;
+    const int tid = threadIdx.x;
+    const int64_t item0 = int64_t(blockIdx.x) * IPB;
+    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+
+    // ---- stage both operands in bitmask order (B de-interleaved and quad-rotated) ----
+    if (!p.left_full || !p.right_full) {
+        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
+        __syncthreads();
+    }
+    for (int it = 0; it < nitems; ++it) {
+        const float* lrow = p.left + (item0 + it) * p.left_stride;
+        const float* rrow = p.right + (item0 + it) * p.right_stride;
+        float* as = smem + it * item_stride;
+        float* bs = as + N;
+        for (int j = tid; j < p.left_count; j += THREADS) {
+            const uint32_t m = p.left_map[j];
+            float v = lrow[m & 0xffffu];
+            if (p.canon_left) v = 0.f + v;
+            if (m >> 31) v = -v;
+            as[(m >> 16) & 0x7fffu] = v;
+        }
+        for (int j = tid; j < p.right_count; j += THREADS) {
+            const uint32_t m = p.right_map[j];
+            float v = rrow[m & 0xffffu];
+            if (p.canon_right) v = 0.f + v;
+            if (m >> 31) v = -v;
+            bs[mfma_b_pos(int((m >> 16) & 0x7fffu))] = v;
+        }
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int it = wave / WPI, tile = wave - it * WPI;
+    if (it < nitems) {
+        const float* As = smem + it * item_stride;
+        const float* Bs = As + N;
+        const int i = lane & 31, h = lane >> 5;
+        const int c_hi = (tile << 5) | i;
+
+        // lane constants: sign masks of the A operand for both parities of |a_hi|, and the
+        // byte offset of A[i ^ k] inside a block, for k = 2s + h
+        uint32_t amask[2][16];
+        uint32_t aoff[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int k = 2 * s2 + h;
+            const int a_lo = i ^ k;
+            int par = 0;
+            for (int pp = 1; pp < 5; ++pp)
+                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+            amask[0][s2] = uint32_t(par) << 31;
+            amask[1][s2] = uint32_t(par ^ (__builtin_popcount(k) & 1)) << 31;
+            aoff[s2] = uint32_t(a_lo) << 2;
+        }
+
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
+        auto one_step = [&](auto odd_tag, int a_hi) {
+            constexpr int ODD = decltype(odd_tag)::value ? 1 : 0;
+            // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
+            uint32_t sp = uint32_t(a_hi) >> 1;
+            sp ^= sp >> 1;
+            sp ^= sp >> 2;
+            sp ^= sp >> 4;
+            sp ^= sp >> 8;
+            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+            const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
+            float bscale = 1.f;
+            if (DEGENERATE) {
+                if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
+            }
+            const int x = a_hi ^ c_hi;
+            const int rot = (x >> 1) & 7;
+            const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 5));
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v v = bp[((h << 2) | q) ^ rot];
+                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+            }
+            const uint32_t abase = uint32_t(a_hi) << 7;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                float a = *reinterpret_cast<const float*>(As_b + abase + aoff[s2]);
+                a = __uint_as_float(__float_as_uint(a) ^ amask[ODD][s2]);
+                float b = __uint_as_float(__float_as_uint(bv[s2]) ^ bmask);
+                if (DEGENERATE) b *= bscale;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        };
+        const int half = H >> 1;
+        for (int t2 = 0; t2 < half; ++t2) one_step(std::false_type{}, (t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
+        for (int t2 = 0; t2 < half; ++t2) one_step(std::true_type{}, (t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+
+        // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
+        float* orow = p.out + (item0 + it) * p.out_stride;
+        const int32_t* om = p.out_map + (c_hi << 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int32_t off = om[c_lo];
+            if (off >= 0) orow[off] = p.beta ? orow[off] + acc[r] : acc[r];
+        }
+    }
+}
+
 }  // namespace gaast

@@ -311,11 +311,16 @@ struct Lowering {
                 const int g = __builtin_popcount(m);
                 if ((omin >> g) & 1ULL) s.i32_a[m] = int32_t(lr.offset(g) + bt.index_of[m]);
             }
-            for (int i = 4; i < n; ++i) {
-                if (d.metric_diag[i] == -1.0) s.neg_hi |= 1u << (i - 4);
-                if (d.metric_diag[i] == 0.0) s.zero_hi |= 1u << (i - 4);
+            // matrix-core variant: f32, n >= 10 (32 result columns per wave), low FIVE vectors +1
+            s.use_mfma = plan.dtype == GAAST_F32 && n >= 10 && n <= 13 && d.metric_diag[4] == 1.0 &&
+                         !(plan.flags & GAAST_FLAG_NO_MFMA);
+            const int lo_bits = s.use_mfma ? 5 : 4;
+            for (int i = lo_bits; i < n; ++i) {
+                if (d.metric_diag[i] == -1.0) s.neg_hi |= 1u << (i - lo_bits);
+                if (d.metric_diag[i] == 0.0) s.zero_hi |= 1u << (i - lo_bits);
             }
             s.degenerate = s.zero_hi != 0;
+            if (s.use_mfma) s.name = "product_dense_mfma[gp n=" + std::to_string(n) + "]";
             touch(res);
             return;
         }

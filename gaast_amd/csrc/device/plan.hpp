@@ -51,6 +51,7 @@ struct Step {
     int left_full = 0, right_full = 0;
     uint32_t neg_hi = 0, zero_hi = 0;
     int degenerate = 0;
+    int use_mfma = 0;
     uint64_t n_entries = 0;  // comp-mul count this step stands for
     // FUSED: the whole plan as one micro-op stream over per-item LDS slabs (u32_a = the stream)
     struct FusedInput {

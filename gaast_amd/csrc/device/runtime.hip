@@ -8,6 +8,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gaast_hip.h"
@@ -199,6 +200,23 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.zero_hi = s.zero_hi;
         p.beta = s.beta;
         p.batch = batch;
+        if (s.use_mfma) {
+            if constexpr (std::is_same<T, float>::value) {
+                const int wpi = 1 << (n - 10);                 // waves per item
+                const int threads = wpi > 4 ? wpi * 64 : 256;
+                const int ipb = (threads / 64) / wpi;
+                const size_t lds = size_t(ipb) * size_t(2 << n) * sizeof(float);
+                if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
+                const int64_t blocks = (batch + ipb - 1) / ipb;
+                auto kern = threads == 256 ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
+                                           : (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>);
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
+                break;
+            }
+        }
         const int lpi = 1 << (n - 4);
         const int threads = lpi > 256 ? lpi : 256;
         const int ipb = threads / lpi;

@@ -119,6 +119,7 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_DEBUG_OVERFLOW 0x1u /* reproduce the debug-build panic of eval.rs:90 (default: release) */
 #define GAAST_FLAG_NO_FUSION 0x2u      /* one kernel per eval.rs arm, every operand materialised (A/B testing) */
 #define GAAST_FLAG_EXACT_ORDER 0x4u    /* never use the dense re-ordered product kernel (bit-exact f64 sums) */
+#define GAAST_FLAG_NO_MFMA 0x8u        /* dense products stay on the vector-FMA kernel (A/B testing) */
 
 typedef struct gaast_program_desc {
     int32_t vec_space_dim;      /* n */
