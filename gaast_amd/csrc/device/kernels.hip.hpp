@@ -420,6 +420,7 @@ struct DenseArgs {
     uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
     int beta;
     int64_t batch;
+    int debug_skip;             // diagnostics only (GAAST_DEBUG_DENSE_SKIP): 2 = no staging, 4 = no write-back
 };
 
 // physical position of blade bitmask m inside an operand's LDS image: blocks of 16, the four
@@ -428,6 +429,40 @@ struct DenseArgs {
 __device__ __forceinline__ int dense_lds_pos(int m) {
     const int x = m >> 4, lo = m & 15;
     return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
+}
+
+
+// Scatter one operand row into its LDS image.  The loop is unrolled by U with all loads of a
+// trip issued before the first use (index-map loads, then the dependent row loads), so a
+// thread has U HBM reads in flight instead of one: staging is latency- not bandwidth-bound.
+template <typename T, int THREADS, typename PosFn>
+__device__ __forceinline__ void stage_operand(const T* __restrict__ row, const uint32_t* __restrict__ map,
+                                              int count, int canon, T* __restrict__ image, int tid, PosFn pos) {
+    constexpr int U = 8;
+    for (int j0 = tid; j0 < count; j0 += THREADS * U) {
+        uint32_t m[U];
+        T v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int j = j0 + k * THREADS;
+            m[k] = j < count ? map[j] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int j = j0 + k * THREADS;
+            v[k] = j < count ? row[m[k] & 0xffffu] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int j = j0 + k * THREADS;
+            if (j < count) {
+                T x = v[k];
+                if (canon) x = T(0) + x;   // the reference's zero-init + add_grades_from copy: 0.0 + x
+                if (m[k] >> 31) x = -x;    // a folded Negation / Reverse / GradeInvolution of this grade
+                image[pos(int((m[k] >> 16) & 0x7fffu))] = x;
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ constexpr int lo_reorder_parity(int a, int b) {
@@ -579,24 +614,11 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
         __syncthreads();
     }
     for (int it = 0; it < nitems; ++it) {
-        const T* lrow = p.left + (item0 + it) * p.left_stride;
-        const T* rrow = p.right + (item0 + it) * p.right_stride;
         T* as = smem + it * item_stride;
-        T* bs = as + N;
-        for (int j = tid; j < p.left_count; j += THREADS) {
-            const uint32_t m = p.left_map[j];
-            T v = lrow[m & 0xffffu];
-            if (p.canon_left) v = zero + v;
-            if (m >> 31) v = -v;  // a folded Negation / Reverse / GradeInvolution of this grade
-            as[dense_lds_pos(int((m >> 16) & 0x7fffu))] = v;
-        }
-        for (int j = tid; j < p.right_count; j += THREADS) {
-            const uint32_t m = p.right_map[j];
-            T v = rrow[m & 0xffffu];
-            if (p.canon_right) v = zero + v;
-            if (m >> 31) v = -v;
-            bs[dense_lds_pos(int((m >> 16) & 0x7fffu))] = v;
-        }
+        stage_operand<T, THREADS>(p.left + (item0 + it) * p.left_stride, p.left_map, p.left_count, p.canon_left, as, tid,
+                                  [](int m) { return dense_lds_pos(m); });
+        stage_operand<T, THREADS>(p.right + (item0 + it) * p.right_stride, p.right_map, p.right_count, p.canon_right,
+                                  as + N, tid, [](int m) { return dense_lds_pos(m); });
     }
     __syncthreads();
 
@@ -701,25 +723,12 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
         __syncthreads();
     }
-    for (int it = 0; it < nitems; ++it) {
-        const float* lrow = p.left + (item0 + it) * p.left_stride;
-        const float* rrow = p.right + (item0 + it) * p.right_stride;
+    for (int it = 0; it < ((p.debug_skip & 2) ? 0 : nitems); ++it) {
         float* as = smem + it * item_stride;
-        float* bs = as + N;
-        for (int j = tid; j < p.left_count; j += THREADS) {
-            const uint32_t m = p.left_map[j];
-            float v = lrow[m & 0xffffu];
-            if (p.canon_left) v = 0.f + v;
-            if (m >> 31) v = -v;
-            as[(m >> 16) & 0x7fffu] = v;
-        }
-        for (int j = tid; j < p.right_count; j += THREADS) {
-            const uint32_t m = p.right_map[j];
-            float v = rrow[m & 0xffffu];
-            if (p.canon_right) v = 0.f + v;
-            if (m >> 31) v = -v;
-            bs[mfma_b_pos(int((m >> 16) & 0x7fffu))] = v;
-        }
+        stage_operand<float, THREADS>(p.left + (item0 + it) * p.left_stride, p.left_map, p.left_count, p.canon_left, as,
+                                      tid, [](int m) { return m; });
+        stage_operand<float, THREADS>(p.right + (item0 + it) * p.right_stride, p.right_map, p.right_count,
+                                      p.canon_right, as + N, tid, [](int m) { return mfma_b_pos(m); });
     }
     __syncthreads();
 
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 
         // lane constants: sign masks of the A operand for both parities of |a_hi|, and the
         // byte offset of A[i ^ k] inside a block, for k = 2s + h
-        uint32_t amask[2][16];
+        uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
         uint32_t aoff[16];
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
@@ -742,18 +751,20 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
             int par = 0;
             for (int pp = 1; pp < 5; ++pp)
                 if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-            amask[0][s2] = uint32_t(par) << 31;
-            amask[1][s2] = uint32_t(par ^ (__builtin_popcount(k) & 1)) << 31;
+            amask[s2] = uint32_t(par) << 31;
             aoff[s2] = uint32_t(a_lo) << 2;
         }
 
+        // one accumulator chain per wave: a dependent f32 MFMA issues back to back (measured: a
+        // second, independent chain changes nothing; what costs is the LDS -> VGPR operand traffic,
+        // about 11 cycles of matrix-pipe time per ds_read_b32 and 24 per ds_read_b128 --
+        // tools/microbench/mfma_rate.hip)
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
-        auto one_step = [&](auto odd_tag, int a_hi) {
-            constexpr int ODD = decltype(odd_tag)::value ? 1 : 0;
+        auto one_step = [&](int a_hi) {
             // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
             uint32_t sp = uint32_t(a_hi) >> 1;
             sp ^= sp >> 1;
@@ -781,15 +792,18 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 float a = *reinterpret_cast<const float*>(As_b + abase + aoff[s2]);
-                a = __uint_as_float(__float_as_uint(a) ^ amask[ODD][s2]);
+                a = __uint_as_float(__float_as_uint(a) ^ amask[s2]);
                 float b = __uint_as_float(__float_as_uint(bv[s2]) ^ bmask);
                 if (DEGENERATE) b *= bscale;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
         };
         const int half = H >> 1;
-        for (int t2 = 0; t2 < half; ++t2) one_step(std::false_type{}, (t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
-        for (int t2 = 0; t2 < half; ++t2) one_step(std::true_type{}, (t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)  // (-1)^(|a_hi| |k|) for odd |a_hi|: flip where |k| is odd, k = 2 s2 + h
+            amask[s2] ^= uint32_t((__builtin_popcount(uint32_t(s2)) + h) & 1) << 31;
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
 
         // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
         float* orow = p.out + (item0 + it) * p.out_stride;
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int r = 0; r < 16; ++r) {
             const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int32_t off = om[c_lo];
-            if (off >= 0) orow[off] = p.beta ? orow[off] + acc[r] : acc[r];
+            if (off >= 0 && !((p.debug_skip & 4) && acc[r] != 12345.f)) orow[off] = p.beta ? orow[off] + acc[r] : acc[r];
         }
     }
 }

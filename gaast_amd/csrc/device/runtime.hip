@@ -200,6 +200,8 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.zero_hi = s.zero_hi;
         p.beta = s.beta;
         p.batch = batch;
+        static const int ddbg = std::getenv("GAAST_DEBUG_DENSE_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_DENSE_SKIP")) : 0;
+        p.debug_skip = ddbg;
         if (s.use_mfma) {
             if constexpr (std::is_same<T, float>::value) {
                 const int wpi = 1 << (n - 10);                 // waves per item
