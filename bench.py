@@ -29,6 +29,10 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 
+# HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 x 1024 +
+# WRITE_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md): (workload, batch) -> bytes
+PMC_TRAFFIC = {("r12", 65536): 2 * 1.04889e6 * 1024 + 1.04858e6 * 1024}
+
 
 def workload_spec(name):
     """(n, metric, dtype name, builder, input grade lists, label)"""
@@ -168,9 +172,8 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     if world > 1:
-        w = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+        from gaast_amd.sharding import max_over_ranks
+        wall = max_over_ranks(wall, device=dev)
     step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     kernel_ms = sum(step_ms) / len(step_ms)
 
@@ -205,6 +208,9 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
                     "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
+        roof["traffic"] = PMC_TRAFFIC.get((args.workload, batch))
+        roof["traffic_source"] = "profiles/r01_r12_mfma_pmc_counters.csv (rocprofv3 --pmc, separate passes)" if roof["traffic"] else None
+        roof["algorithmic_bytes_per_launch"] = bytes_item * batch
         roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
         roof["kernel_ms"] = kernel_ms
         roof["flops_per_item"] = flops_item
