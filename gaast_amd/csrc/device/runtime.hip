@@ -209,12 +209,12 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 const int ipb = (threads / 64) / wpi;
                 const size_t lds = size_t(ipb) * size_t(2 << n) * sizeof(float);
                 if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
-                const int64_t blocks = (batch + ipb - 1) / ipb;
                 auto kern = threads == 256 ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
                                            : (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>);
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                const int64_t blocks = (batch + ipb - 1) / ipb;
                 hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
                 break;
             }
