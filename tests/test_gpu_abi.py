@@ -1,0 +1,180 @@
+"""The C ABI exercised the way a foreign host (the Rust shim of INTEGRATION.md) would use it:
+flat program structs built by hand, explicit comp-mul lists, wrapped device memory, strides,
+shared (batch-1) operands, f32 programs, malformed programs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gaast_amd as ga
+from gaast_amd import _lib
+from helpers import (HipBackend, OracleBackend, bits_to_row, full_grades, gp_bits, hip_eval_batch, n_choose_k,
+                     oracle_eval_batch, row_to_bits, rows_of)
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_program(spec, kind_override=None, flags=0, dtype=_lib.F64):
+    """Re-create the program of `spec` through raw structs, as a host that only sees the public
+    read API would: explicit lists, product_kind = EXPLICIT (the closure is opaque to it)."""
+    L = _lib.lib()
+    d = spec.program_desc()
+    nodes = (_lib.NodeDesc * d.n_nodes)()
+    keep = []
+    for i in range(d.n_nodes):
+        src = d.nodes[i]
+        nodes[i].opcode, nodes[i].child0, nodes[i].child1 = src.opcode, src.child0, src.child1
+        nodes[i].minimal_grade_mask, nodes[i].vec_space_dim = src.minimal_grade_mask, src.vec_space_dim
+        nodes[i].input_slot = src.input_slot
+        nodes[i].product_kind = _lib.PROD_EXPLICIT if kind_override is None else kind_override
+        nodes[i].n_comp_muls = src.n_comp_muls
+        if src.opcode == _lib.OP_PRODUCT and src.n_comp_muls:
+            arr = (_lib.CompMul * src.n_comp_muls)()
+            C.memmove(arr, src.comp_muls, C.sizeof(_lib.CompMul) * src.n_comp_muls)
+            keep.append(arr)
+            nodes[i].comp_muls = arr
+    out = _lib.ProgramDesc()
+    out.vec_space_dim, out.metric_diag, out.dtype = d.vec_space_dim, d.metric_diag, dtype
+    out.n_nodes, out.nodes, out.root = d.n_nodes, nodes, d.root
+    out.n_inputs, out.inputs, out.flags = d.n_inputs, d.inputs, flags
+    keep.append(nodes)
+    return out, keep
+
+
+def _run_raw(desc, inputs, batch, out_dim):
+    L = _lib.lib()
+    _lib.init_device()
+    prog = C.c_void_p()
+    _lib.check(L.gaast_hip_program_create(C.byref(desc), C.byref(prog)))
+    mask, rl = C.c_uint64(), C.c_int64()
+    _lib.check(L.gaast_hip_program_output_info(prog, C.byref(mask), C.byref(rl)))
+    out = ga.DeviceMV.alloc(out_dim, ga.GradeSet(mask.value), batch, desc.dtype)
+    handles = (C.c_void_p * max(1, len(inputs)))(*[m._h for m in inputs])
+    _lib.check(L.gaast_hip_eval(prog, handles, len(inputs), batch, out._h))
+    _lib.check(L.gaast_hip_synchronize())
+    rows = out.download_rows()
+    names = [L.gaast_hip_program_launch_name(prog, i).decode() for i in range(L.gaast_hip_program_num_launches(prog))]
+    _lib.check(L.gaast_hip_program_destroy(prog))
+    return rows, names
+
+
+def test_explicit_lists_from_a_foreign_host_are_exact():
+    """BASELINE config 5 through hand-built structs (product_kind unknown): bit-exact."""
+    batch = 300
+    rng = np.random.default_rng(5)
+    build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, [0, 2, 4], 5), B.input(1, [1], 5))
+    cga = [1.0, 1.0, 1.0, 1.0, -1.0]
+    rows = {0: rows_of(5, [0, 2, 4], batch, rng), 1: rows_of(5, [1], batch, rng)}
+    want, _ = oracle_eval_batch(build, cga, rows, batch)
+    spec = build(HipBackend()).specialize(cga, materialize_limit=0)
+    desc, keep = _raw_program(spec)
+    ins = [ga.DeviceMV.from_rows(5, [0, 2, 4], rows[0]), ga.DeviceMV.from_rows(5, [1], rows[1])]
+    got, names = _run_raw(desc, ins, batch, 5)
+    assert np.array_equal(got, want), names
+
+
+def test_explicit_dense_list_without_kind_hint_stays_exact_and_with_hint_goes_dense():
+    n, batch = 6, 17
+    rng = np.random.default_rng(6)
+    build = lambda B: B.input(0, full_grades(n), n) * B.input(1, full_grades(n), n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    want, _ = oracle_eval_batch(build, n, rows, batch)
+    spec = build(HipBackend()).specialize(n, materialize_limit=0)
+    ins = [ga.DeviceMV.from_rows(n, full_grades(n), rows[s]) for s in range(2)]
+    desc, keep = _raw_program(spec)                                   # kind unknown -> exact kernels
+    got, names = _run_raw(desc, ins, batch, n)
+    assert not any("dense" in x for x in names) and np.array_equal(got, want)
+    desc, keep = _raw_program(spec, kind_override=_lib.PROD_GEOMETRIC)  # host vouches: geometric product
+    got, names = _run_raw(desc, ins, batch, n)
+    assert any("dense" in x for x in names) and np.allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_wrapped_memory_with_row_stride_and_shared_operand():
+    """Rows inside a wider caller-owned buffer (row_stride > row_len); left operand shared (batch 1)."""
+    import torch
+    n, batch = 7, 19
+    rng = np.random.default_rng(7)
+    a = rows_of(n, full_grades(n), 1, rng)
+    b = rows_of(n, full_grades(n), batch, rng)
+    build = lambda B: B.input(0, full_grades(n), n) * B.input(1, full_grades(n), n)
+    want, _ = oracle_eval_batch(build, n, {0: a, 1: b}, batch)
+    ga.init_device()
+    L = _lib.lib()
+    N = 1 << n
+    big_b = torch.full((batch, N + 24), 777.0, dtype=torch.float64, device="cuda")
+    big_o = torch.full((batch, N + 8), -5.0, dtype=torch.float64, device="cuda")
+    big_b[:, :N] = torch.from_numpy(b).cuda()
+    hb, ho = C.c_void_p(), C.c_void_p()
+    mask = (1 << (n + 1)) - 1
+    _lib.check(L.gaast_hip_mv_wrap(C.c_void_p(big_b.data_ptr()), n, mask, batch, _lib.F64, N + 24, C.byref(hb)))
+    _lib.check(L.gaast_hip_mv_wrap(C.c_void_p(big_o.data_ptr()), n, mask, batch, _lib.F64, N + 8, C.byref(ho)))
+    wb = ga.DeviceMV(hb, n, mask, batch, _lib.F64, keep=big_b)
+    wo = ga.DeviceMV(ho, n, mask, batch, _lib.F64, keep=big_o)
+    spec = build(HipBackend()).specialize(n)
+    spec.eval_batch([ga.DeviceMV.from_rows(n, full_grades(n), a), wb], batch, out=wo)
+    torch.cuda.synchronize()
+    L.gaast_hip_synchronize()
+    res = big_o.cpu().numpy()
+    assert np.allclose(res[:, :N], want, rtol=0, atol=1e-12)
+    assert np.all(res[:, N:] == -5.0), "wrote outside the rows"
+    assert np.all(big_b.cpu().numpy()[:, N:] == 777.0)
+
+
+@pytest.mark.parametrize("name,tol", [("cfg1", 1e-5), ("sandwich", 1e-4)])
+def test_f32_extension_of_the_fused_kernel(name, tol):
+    batch = 257
+    rng = np.random.default_rng(9)
+    if name == "cfg1":
+        build = lambda B: (B.input(0, full_grades(3), 3) + B.input(1, full_grades(3), 3) * B.input(2, full_grades(3), 3)).g(2)
+        alg, rows = 3, {s: rows_of(3, full_grades(3), batch, rng, np.float32) for s in range(3)}
+    else:
+        build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, [0, 2, 4], 5), B.input(1, [1], 5))
+        alg = [1.0, 1.0, 1.0, 1.0, -1.0]
+        rows = {0: rows_of(5, [0, 2, 4], batch, rng, np.float32), 1: rows_of(5, [1], batch, rng, np.float32)}
+    want, _ = oracle_eval_batch(build, alg, rows, batch)
+    got, _, spec = hip_eval_batch(build, alg, rows, batch, dtype=ga.F32)
+    assert any("ast_fused" in l for l in spec.launches())
+    assert got.dtype == np.float32 and np.allclose(got, want, rtol=0, atol=tol)
+
+
+def test_malformed_programs_are_rejected_not_executed():
+    L = _lib.lib()
+    _lib.init_device()
+    spec = (ga.mv(ga.Input(0, [1], 3)) * ga.mv(ga.Input(1, [1], 3))).specialize(3)
+    desc, keep = _raw_program(spec)
+    desc.nodes[2].child0 = 2                      # not post-order: a node referring to itself
+    prog = C.c_void_p()
+    assert L.gaast_hip_program_create(C.byref(desc), C.byref(prog)) == 1   # INVALID_PROGRAM
+    desc, keep = _raw_program(spec)
+    desc.nodes[2].comp_muls[0].left_index = 99   # index beyond C(3,1)
+    assert L.gaast_hip_program_create(C.byref(desc), C.byref(prog)) == 1
+    desc, keep = _raw_program(spec)
+    desc.nodes[0].input_slot = 7                 # slot out of range
+    assert L.gaast_hip_program_create(C.byref(desc), C.byref(prog)) == 1
+    # wrong grade set / dtype / batch of a bound input -> INVALID_ARGUMENT at eval
+    with pytest.raises(ga.GaastError) as ei:
+        spec.eval_batch([np.zeros((4, 3)), ga.DeviceMV.alloc(3, [2], 4)], 4)
+    assert ei.value.status_name == "INVALID_ARGUMENT"
+    with pytest.raises(ga.GaastError):
+        spec.eval_batch([np.zeros((4, 3)), np.zeros((3, 3))], 4)
+
+
+def test_q2_missing_grade_is_a_status():
+    """A GradeProjection inside an Addition chain whose shared child wants more grades than the
+    result buffer holds: the reference panics in grade_slice_mut (graded.rs:192-194)."""
+    def build(B):
+        a = B.input(0, [1], 3)
+        b = B.input(1, [1], 3)
+        p = a * b                      # {0,2}, shared
+        return p.g(0) + (p * p).g(0)   # root {0}; p is asked for {0,2} by the product, {0} by the projection
+    rows = {0: np.array([[1.0, 2.0, 3.0]]), 1: np.array([[0.5, -1.0, 2.0]])}
+    try:
+        want, _ = oracle_eval_batch(build, 3, rows, 1)
+        got, _, _ = hip_eval_batch(build, 3, rows, 1)
+        assert np.array_equal(got, want)
+    except Exception as ref:
+        from oracle import pyoracle as og
+        assert isinstance(ref, og.OraclePanic) and ref.code == 1
+        with pytest.raises(ga.GaastError) as ei:
+            hip_eval_batch(build, 3, rows, 1)
+        assert ei.value.status_name == "MISSING_GRADE"
