@@ -410,10 +410,11 @@ struct DenseArgs {
     const T* right;
     T* out;
     int64_t left_stride, right_stride, out_stride;
-    const uint32_t* left_map;   // per loaded component: row offset | bitmask << 16 | negate << 31
+    const uint32_t* left_map;   // per loaded component: row offset | LDS image position << 16 | negate << 31
     const uint32_t* right_map;
     int left_count, right_count;
     int left_full, right_full;  // 1: every blade is loaded, no zero fill needed
+    int left_contig, right_contig;  // 1: row offsets are 0,1,2,... and rows are 16-byte aligned: vector loads
     const int32_t* out_map;     // per bitmask: offset in the out row, or -1
     int canon_left, canon_right;
     int n;                      // vector-space dimension, 4 <= n
@@ -432,34 +433,79 @@ __device__ __forceinline__ int dense_lds_pos(int m) {
 }
 
 
-// Scatter one operand row into its LDS image.  The loop is unrolled by U with all loads of a
-// trip issued before the first use (index-map loads, then the dependent row loads), so a
-// thread has U HBM reads in flight instead of one: staging is latency- not bandwidth-bound.
-template <typename T, int THREADS, typename PosFn>
-__device__ __forceinline__ void stage_operand(const T* __restrict__ row, const uint32_t* __restrict__ map,
-                                              int count, int canon, T* __restrict__ image, int tid, PosFn pos) {
-    constexpr int U = 8;
-    for (int j0 = tid; j0 < count; j0 += THREADS * U) {
+// Scatter the operand rows of `nitems` items into their LDS images.  A map word is
+//   row offset [15:0] | position in the LDS image [30:16] | negate [31]
+// (the position is computed on the host for the kernel that consumes the image).  Loads of a
+// trip are all issued before the first use.  When the offsets are simply 0, 1, 2, ... (an
+// operand holding every blade) four consecutive components move per 16-byte load.
+template <typename T, int THREADS>
+__device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_t stride, const uint32_t* __restrict__ map,
+                                               int count, int contig4, int canon, T* __restrict__ images,
+                                               int image_stride, int nitems, int tid) {
+    constexpr int U = 4;
+    if (contig4) {
+        const int total4 = (nitems * count) >> 2;  // count % 4 == 0
+        const int count4 = count >> 2;
+        for (int e0 = tid; e0 < total4; e0 += THREADS * U) {
+            uint4 m[U];
+            T v[U][4];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + k * THREADS;
+                if (e < total4) {
+                    const int it = e / count4, j4 = e - it * count4;
+                    m[k] = reinterpret_cast<const uint4*>(map)[j4];
+                    const T* rp = src + int64_t(it) * stride + (j4 << 2);
+                    if (sizeof(T) == 4) {
+                        const float4 f = *reinterpret_cast<const float4*>(rp);
+                        v[k][0] = T(f.x); v[k][1] = T(f.y); v[k][2] = T(f.z); v[k][3] = T(f.w);
+                    } else {
+                        const double2 d0 = reinterpret_cast<const double2*>(rp)[0], d1 = reinterpret_cast<const double2*>(rp)[1];
+                        v[k][0] = T(d0.x); v[k][1] = T(d0.y); v[k][2] = T(d1.x); v[k][3] = T(d1.y);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + k * THREADS;
+                if (e < total4) {
+                    const int it = e / count4;
+                    T* img = images + it * image_stride;
+                    const uint32_t mm[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        T x = v[k][c];
+                        if (canon) x = T(0) + x;  // the reference's zero-init + add_grades_from copy: 0.0 + x
+                        if (mm[c] >> 31) x = -x;  // a folded Negation / Reverse / GradeInvolution of this grade
+                        img[(mm[c] >> 16) & 0x7fffu] = x;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const int total = nitems * count;
+    for (int e0 = tid; e0 < total; e0 += THREADS * U) {
         uint32_t m[U];
         T v[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int j = j0 + k * THREADS;
-            m[k] = j < count ? map[j] : 0u;
+            const int e = e0 + k * THREADS;
+            m[k] = e < total ? map[e % count] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int j = j0 + k * THREADS;
-            v[k] = j < count ? row[m[k] & 0xffffu] : T(0);
+            const int e = e0 + k * THREADS;
+            v[k] = e < total ? src[int64_t(e / count) * stride + (m[k] & 0xffffu)] : T(0);
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int j = j0 + k * THREADS;
-            if (j < count) {
+            const int e = e0 + k * THREADS;
+            if (e < total) {
                 T x = v[k];
-                if (canon) x = T(0) + x;   // the reference's zero-init + add_grades_from copy: 0.0 + x
-                if (m[k] >> 31) x = -x;    // a folded Negation / Reverse / GradeInvolution of this grade
-                image[pos(int((m[k] >> 16) & 0x7fffu))] = x;
+                if (canon) x = T(0) + x;
+                if (m[k] >> 31) x = -x;
+                images[(e / count) * image_stride + ((m[k] >> 16) & 0x7fffu)] = x;
             }
         }
     }
@@ -601,69 +647,76 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
     const int N = 1 << n;
     const int hbits = n - 4;
     const int LPI = 1 << hbits;                   // lanes per item
-    const int IPB = THREADS >> hbits;             // items per block (>= 1)
+    const int IPB = THREADS >> hbits;             // items per group (>= 1)
     const int item_stride = 2 * N + (IPB > 1 ? 4 : 0);  // +16 B: de-phase the items' A broadcasts
     const int tid = threadIdx.x;
-    const int64_t item0 = int64_t(blockIdx.x) * IPB;
-    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
     const T zero = T(0);
-
-    // ---- stage both operands of every item of the block, in bitmask order ----
-    if (!p.left_full || !p.right_full) {
-        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
-        __syncthreads();
-    }
-    for (int it = 0; it < nitems; ++it) {
-        T* as = smem + it * item_stride;
-        stage_operand<T, THREADS>(p.left + (item0 + it) * p.left_stride, p.left_map, p.left_count, p.canon_left, as, tid,
-                                  [](int m) { return dense_lds_pos(m); });
-        stage_operand<T, THREADS>(p.right + (item0 + it) * p.right_stride, p.right_map, p.right_count, p.canon_right,
-                                  as + N, tid, [](int m) { return dense_lds_pos(m); });
-    }
-    __syncthreads();
+    const int64_t num_groups = (p.batch + IPB - 1) / IPB;
 
     const int it = tid >> hbits;
     const int c_hi = tid & (LPI - 1);
-    if (it < nitems) {
-        const T* As = smem + it * item_stride;
-        const T* Bs = As + N;
-        BlockStep<T> acc;
-        acc.init();
-
-        // Two passes: first the A blocks with |a_hi| even, then those with |a_hi| odd -- each pass
-        // has ONE straight-line body (the sign pattern of the 16x16 block depends on that parity),
-        // so the accumulators never cross a branch.  a_hi = 2i + (parity(i) ^ pass).
-        auto one_step = [&](auto odd_tag, int a_hi) {
-            constexpr bool ODD = decltype(odd_tag)::value;
-            // wave-uniform part of the block sign
-            uint32_t sp = uint32_t(a_hi) >> 1;
-            sp ^= sp >> 1;
-            sp ^= sp >> 2;
-            sp ^= sp >> 4;
-            sp ^= sp >> 8;
-            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
-                                __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-            // lane part
-            const uint32_t sbit = (u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u;
-            T sgn = sbit ? T(-1) : T(1);
-            if (DEGENERATE) {
-                if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) sgn = zero;
-            }
-            acc.template step<ODD>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
-        };
-        const int half = LPI >> 1;
-        for (int i = 0; i < half; ++i) one_step(std::false_type{}, (i << 1) | (__builtin_popcount(uint32_t(i)) & 1));
-        for (int i = 0; i < half; ++i) one_step(std::true_type{}, (i << 1) | ((__builtin_popcount(uint32_t(i)) & 1) ^ 1));
-
-        // ---- scatter the 16 accumulators to their positions in the graded row ----
-        T* orow = p.out + (item0 + it) * p.out_stride;
-        const int32_t* om = p.out_map + (c_hi << 4);
+    int32_t om[16];  // where this lane's 16 results go in the graded row (the same for every group)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int32_t off = om[i];
-            if (off >= 0) orow[off] = p.beta ? orow[off] + acc.get(i) : acc.get(i);
+    for (int i = 0; i < 16; ++i) om[i] = p.out_map[(c_hi << 4) + i];
+
+    // persistent workgroups: each walks the groups blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (int64_t grp = blockIdx.x; grp < num_groups; grp += gridDim.x) {
+        const int64_t item0 = grp * IPB;
+        const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+        // ---- both operands of every item of the group into LDS, in bitmask order ----
+        if (!(p.debug_skip & 2)) {
+            if (!p.left_full || !p.right_full) {
+                for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
+                __syncthreads();
+            }
+            stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, nitems, tid);
+            stage_operands<T, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
         }
+        __syncthreads();
+
+        if (it < nitems) {
+            const T* As = smem + it * item_stride;
+            const T* Bs = As + N;
+            BlockStep<T> acc;
+            acc.init();
+
+            // Two passes: first the A blocks with |a_hi| even, then those with |a_hi| odd -- each
+            // pass has ONE straight-line body (the sign pattern of the 16x16 block depends on that
+            // parity), so the accumulators never cross a branch.  a_hi = 2i + (parity(i) ^ pass).
+            auto one_step = [&](auto odd_tag, int a_hi) {
+                constexpr bool ODD = decltype(odd_tag)::value;
+                // wave-uniform part of the block sign
+                uint32_t sp = uint32_t(a_hi) >> 1;
+                sp ^= sp >> 1;
+                sp ^= sp >> 2;
+                sp ^= sp >> 4;
+                sp ^= sp >> 8;
+                const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+                const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                    __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+                // lane part
+                const uint32_t sbit = (u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u;
+                T sgn = sbit ? T(-1) : T(1);
+                if (DEGENERATE) {
+                    if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) sgn = zero;
+                }
+                acc.template step<ODD>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
+            };
+            const int half = LPI >> 1;
+            for (int i = 0; i < half; ++i) one_step(std::false_type{}, (i << 1) | (__builtin_popcount(uint32_t(i)) & 1));
+            for (int i = 0; i < half; ++i) one_step(std::true_type{}, (i << 1) | ((__builtin_popcount(uint32_t(i)) & 1) ^ 1));
+
+            // ---- scatter the 16 accumulators to their positions in the graded row ----
+            T* orow = p.out + (item0 + it) * p.out_stride;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int32_t off = om[i];
+                if (off >= 0) orow[off] = p.beta ? orow[off] + acc.get(i) : acc.get(i);
+            }
+        }
+        __syncthreads();  // the LDS image is rewritten by the next group
     }
 }
 
@@ -723,12 +776,11 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
         __syncthreads();
     }
-    for (int it = 0; it < ((p.debug_skip & 2) ? 0 : nitems); ++it) {
-        float* as = smem + it * item_stride;
-        stage_operand<float, THREADS>(p.left + (item0 + it) * p.left_stride, p.left_map, p.left_count, p.canon_left, as,
-                                      tid, [](int m) { return m; });
-        stage_operand<float, THREADS>(p.right + (item0 + it) * p.right_stride, p.right_map, p.right_count,
-                                      p.canon_right, as + N, tid, [](int m) { return mfma_b_pos(m); });
+    if (!(p.debug_skip & 2)) {
+        stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, nitems, tid);
+        stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
     }
     __syncthreads();
 

@@ -294,26 +294,44 @@ struct Lowering {
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
             const int n = d.vec_space_dim;
-            // entry: row offset | blade bitmask << 16 | (negate while staging) << 31
-            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, std::vector<uint32_t>& map, int* full) {
+            // matrix-core variant: f32, n >= 10 (32 result columns per wave), low FIVE vectors +1
+            s.use_mfma = plan.dtype == GAAST_F32 && n >= 10 && n <= 13 && d.metric_diag[4] == 1.0 &&
+                         !(plan.flags & GAAST_FLAG_NO_MFMA);
+            // position of blade m in the LDS image the kernel reads (mirrors kernels.hip.hpp)
+            auto vec_pos = [](uint32_t m) {  // dense_lds_pos
+                const uint32_t x = m >> 4, lo = m & 15;
+                return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
+            };
+            auto mfma_b_pos = [](uint32_t m) {
+                const uint32_t x = m >> 5, k = m & 31;
+                const uint32_t lq = ((k & 1) << 2) | (k >> 3);
+                return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
+            };
+            // entry: row offset | image position << 16 | (negate while staging) << 31
+            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, bool right, std::vector<uint32_t>& map,
+                                 int* full, int* contig) {
+                bool seq = true;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
                     const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
-                    for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i)
-                        map.push_back(uint32_t(lay.offset(k) + i) | (bt.blade_of[size_t(k)][i] << 16) | sgn);
+                    for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
+                        const uint32_t blade = bt.blade_of[size_t(k)][i];
+                        const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade) : vec_pos(blade);
+                        const uint32_t off = uint32_t(lay.offset(k) + i);
+                        seq = seq && off == map.size();
+                        map.push_back(off | (pos << 16) | sgn);
+                    }
                 }
                 *full = map.size() == (size_t(1) << n);
+                *contig = seq && map.size() % 4 == 0 && !map.empty();
             };
-            build_map(ll, lmin & ll.mask, flip_l, s.u32_a, &s.left_full);
-            build_map(lrr, rmin & lrr.mask, flip_r, s.u32_b, &s.right_full);
+            build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full, &s.left_contig);
+            build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full, &s.right_contig);
             s.i32_a.assign(size_t(1) << n, -1);
             for (uint32_t m = 0; m < (1u << n); ++m) {
                 const int g = __builtin_popcount(m);
                 if ((omin >> g) & 1ULL) s.i32_a[m] = int32_t(lr.offset(g) + bt.index_of[m]);
             }
-            // matrix-core variant: f32, n >= 10 (32 result columns per wave), low FIVE vectors +1
-            s.use_mfma = plan.dtype == GAAST_F32 && n >= 10 && n <= 13 && d.metric_diag[4] == 1.0 &&
-                         !(plan.flags & GAAST_FLAG_NO_MFMA);
             const int lo_bits = s.use_mfma ? 5 : 4;
             for (int i = lo_bits; i < n; ++i) {
                 if (d.metric_diag[i] == -1.0) s.neg_hi |= 1u << (i - lo_bits);

@@ -192,6 +192,12 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.right_count = int(s.u32_b.size());
         p.left_full = s.left_full;
         p.right_full = s.right_full;
+        // vector loads need 16-byte aligned rows: base pointer and row stride
+        auto aligned = [](const void* ptr, int64_t stride) {
+            return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((size_t(stride) * sizeof(T)) % 16 == 0);
+        };
+        p.left_contig = s.left_contig && aligned(a.ptr, a.stride);
+        p.right_contig = s.right_contig && aligned(b.ptr, b.stride);
         p.out_map = static_cast<const int32_t*>(s.d_i32);
         p.canon_left = s.canon_a;
         p.canon_right = s.canon_b;
@@ -224,12 +230,18 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         const int ipb = threads / lpi;
         const size_t lds = size_t(ipb) * size_t(2 * (1 << n) + (ipb > 1 ? 4 : 0)) * sizeof(T);
         if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
-        const int64_t blocks = (batch + ipb - 1) / ipb;
+        const int64_t groups = (batch + ipb - 1) / ipb;
         auto kern = threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256> : &k_gp_dense<T, false, 256>)
                                    : (s.degenerate ? &k_gp_dense<T, true, 512> : &k_gp_dense<T, false, 512>);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        // persistent workgroups: as many as are resident at once (register- and LDS-limited)
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
+        if (per_cu < 1) per_cu = 1;
+        int64_t blocks = int64_t(g_num_cu) * per_cu;
+        if (blocks > groups) blocks = groups;
         hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
         break;
     }
