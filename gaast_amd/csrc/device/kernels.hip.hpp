@@ -146,23 +146,23 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 // a Product is its comp-mul list grouped by result component, each component's entries in
 // the reference's order, so all roundings are those of eval.rs:82.
 //
-// line = 8 x u32.  word 0 = header, [31:28] kind:
-//   LINE_MACS  dst[11:0] begin[12] fresh[13] end[14] count[17:15]; words 1..7 = MAC slots
+// line = 32 x u32 (128 bytes, two s_load_dwordx16).  word 0 = header, [31:28] kind:
+//   LINE_MACS  dst[11:0] begin[12] fresh[13] end[14] count[18:15] (1..10); words 2+3k, 3+3k, 4+3k =
+//              slot k: left BYTE offset, right BYTE offset, sign mask (0 or 0x80000000), all
+//              pre-computed on the host so that a slot costs no scalar instruction at all:
+//                  acc = acc + ((slab[l] * slab[r]) ^ sign)            == + (l*r)*(+-1.0), exact
 //              begin: acc = fresh ? 0.0 : slab[dst];   end: slab[dst] = acc
-//              MAC slot: l[11:0] r[23:12] c[26:24]:  acc = acc + (slab[l] * slab[r]) * coeff(c)
-//              with coeff(0) = +1, coeff(1) = -1, c >= 2 -> general table[c-2].
-//              LINE_MACS: 7 sign-only slots (coefficients +-1, the sign applied by flipping the
-//              product's sign bit = multiplying by +-1.0), straight-line, all 14 operands fetched
-//              before the first multiply; LINE_MACS_CNT: same slots, counted, for rows that
-//              accumulate into an existing value; LINE_MACS_GEN: counted, multiplies by the
-//              coefficient like eval.rs:82.
-//   LINE_MISC  count[17:15]; words 1..count = element-wise micro-ops, [31:28] opcode:
+//              The body is straight-line per count; all operands are fetched before the first multiply.
+//   LINE_MACS_GEN  same header, count <= 10; word 2+3k = left element | right element << 12,
+//              word 3+3k = coefficient id (0: +1, 1: -1, >= 2: table[id-2]); multiplies by the
+//              coefficient like eval.rs:82 (general metrics; rare).
+//   LINE_MISC  count[20:15] (<= 30); words 2.. = element-wise micro-ops, [31:28] opcode:
 //              ADD dst[11:0] src[23:12]   slab[dst] = slab[dst] + slab[src]     (graded.rs:74)
 //              NEG dst                    slab[dst] = -slab[dst]                 (graded.rs:63)
 //              ZERO dst count[23:12]      slab[dst..dst+count) = 0.0             (graded.rs:195-201)
 //              INV / SQRT dst             eval.rs:106-109
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, LINE_MACS_CNT = 4 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3 };
 enum : uint32_t { UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5, UOP_INV = 6, UOP_SQRT = 7 };
 
 constexpr int FUSED_MAX_INPUTS = 8;
@@ -173,7 +173,7 @@ constexpr int FUSED_THREADS = FUSED_ITEMS * FUSED_GROUPS;
 
 template <typename T>
 struct FusedArgs {
-    const uint32_t* prog;      // 8-word lines
+    const uint32_t* prog;      // 32-word lines
     const uint32_t* phase_tab; // per (phase, wave): first line, number of lines
     int n_phases;
     T coeff[6];             // general coefficients (c >= 2)
@@ -217,14 +217,9 @@ __device__ __forceinline__ void fused_misc(uint32_t w, T* __restrict__ my) {
     }
 }
 
-// Sign-only MAC slot (LINE_MACS / LINE_MACS_CNT): byte offsets, pre-scaled on the host:
-//   [14:0] left byte offset   [29:15] right byte offset   [31] negate the product
-// General slot (LINE_MACS_GEN): [11:0] left element  [23:12] right element  [26:24] coefficient id
-__device__ __forceinline__ float flip_sign_bit(float t, uint32_t w) {
-    return __uint_as_float(__float_as_uint(t) ^ (w & 0x80000000u));
-}
-__device__ __forceinline__ double flip_sign_bit(double t, uint32_t w) {
-    return __hiloint2double(__double2hiint(t) ^ int(w & 0x80000000u), __double2loint(t));
+__device__ __forceinline__ float xor_sign(float t, uint32_t mask) { return __uint_as_float(__float_as_uint(t) ^ mask); }
+__device__ __forceinline__ double xor_sign(double t, uint32_t mask) {
+    return __hiloint2double(__double2hiint(t) ^ int(mask), __double2loint(t));
 }
 
 template <typename T>
@@ -232,32 +227,43 @@ __device__ __forceinline__ T lds_at(const T* my, uint32_t byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(my) + byte_off);
 }
 
-// A line of CNT sign-only slots, straight-line: 2*CNT LDS reads in flight, then the sum.
+struct FusedLine {
+    uint4 q[8];  // 32 words, wave-uniform (scalar registers)
+    __device__ __forceinline__ uint32_t word(int i) const {
+        const uint4& v = q[i >> 2];
+        return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w;
+    }
+};
+
+// CNT sign-only slots, straight-line: 2*CNT LDS reads in flight, then the sum.
 template <typename T, int CNT>
-__device__ __forceinline__ void fused_mac_n(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc) {
+__device__ __forceinline__ void fused_mac_n(uint32_t h, const FusedLine& L, T* __restrict__ my, T& acc) {
     T l[CNT], r[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
-        l[k] = lds_at<T>(my, w[k] & 0x7fffu);
-        r[k] = lds_at<T>(my, (w[k] >> 15) & 0x7fffu);
+        l[k] = lds_at<T>(my, L.word(2 + 3 * k));
+        r[k] = lds_at<T>(my, L.word(3 + 3 * k));
     }
     T* d = my + (h & 0xfffu);
     if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) acc = acc + flip_sign_bit(l[k] * r[k], w[k]);  // (l*r)*(+-1.0), exact
+    for (int k = 0; k < CNT; ++k) acc = acc + xor_sign(l[k] * r[k], L.word(4 + 3 * k));  // (l*r)*(+-1.0), exact
     if (h & (1u << 14)) *d = acc;
 }
 
 template <typename T>
-__device__ __forceinline__ void fused_mac_full(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc) {
-    switch ((h >> 15) & 7u) {  // wave-uniform: one jump per line, then straight-line code
-    case 7: fused_mac_n<T, 7>(h, w, my, acc); break;
-    case 6: fused_mac_n<T, 6>(h, w, my, acc); break;
-    case 5: fused_mac_n<T, 5>(h, w, my, acc); break;
-    case 4: fused_mac_n<T, 4>(h, w, my, acc); break;
-    case 3: fused_mac_n<T, 3>(h, w, my, acc); break;
-    case 2: fused_mac_n<T, 2>(h, w, my, acc); break;
-    case 1: fused_mac_n<T, 1>(h, w, my, acc); break;
+__device__ __forceinline__ void fused_mac_line(uint32_t h, const FusedLine& L, T* __restrict__ my, T& acc) {
+    switch ((h >> 15) & 15u) {  // wave-uniform: one jump per line, then straight-line code
+    case 10: fused_mac_n<T, 10>(h, L, my, acc); break;
+    case 9: fused_mac_n<T, 9>(h, L, my, acc); break;
+    case 8: fused_mac_n<T, 8>(h, L, my, acc); break;
+    case 7: fused_mac_n<T, 7>(h, L, my, acc); break;
+    case 6: fused_mac_n<T, 6>(h, L, my, acc); break;
+    case 5: fused_mac_n<T, 5>(h, L, my, acc); break;
+    case 4: fused_mac_n<T, 4>(h, L, my, acc); break;
+    case 3: fused_mac_n<T, 3>(h, L, my, acc); break;
+    case 2: fused_mac_n<T, 2>(h, L, my, acc); break;
+    case 1: fused_mac_n<T, 1>(h, L, my, acc); break;
     default: {
         T* d = my + (h & 0xfffu);
         if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
@@ -266,23 +272,19 @@ __device__ __forceinline__ void fused_mac_full(uint32_t h, const uint32_t (&w)[7
     }
 }
 
-// Counted variants (rows accumulating into an existing value, general coefficients): rare.
-template <typename T, bool GENERAL>
-__device__ __forceinline__ void fused_mac_counted(uint32_t h, const uint32_t (&w)[7], T* __restrict__ my, T& acc,
+// General coefficients: literal eval.rs:82 arithmetic, counted (rare path).
+template <typename T>
+__device__ __forceinline__ void fused_mac_general(uint32_t h, const FusedLine& L, T* __restrict__ my, T& acc,
                                                   const T* __restrict__ ctab) {
-    const uint32_t cnt = (h >> 15) & 7u;
+    const uint32_t cnt = (h >> 15) & 15u;
     T* d = my + (h & 0xfffu);
     if (h & (1u << 12)) acc = (h & (1u << 13)) ? T(0) : *d;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 10; ++k) {
         if (uint32_t(k) < cnt) {
-            if (GENERAL) {
-                const T t = my[w[k] & 0xfffu] * my[(w[k] >> 12) & 0xfffu];
-                acc = acc + t * ctab[(w[k] >> 24) & 7u];  // eval.rs:82
-            } else {
-                const T t = lds_at<T>(my, w[k] & 0x7fffu) * lds_at<T>(my, (w[k] >> 15) & 0x7fffu);
-                acc = acc + flip_sign_bit(t, w[k]);
-            }
+            const uint32_t w = L.word(2 + 3 * k);
+            const T t = my[w & 0xfffu] * my[(w >> 12) & 0xfffu];
+            acc = acc + t * ctab[L.word(3 + 3 * k) & 7u];
         }
     }
     if (h & (1u << 14)) *d = acc;
@@ -327,37 +329,38 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ast_fused(FusedArgs<T> p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     T* my = smem + (tid & 63) * S;
     T acc = T(0);
-    // Program lines come through the scalar cache (the stream is wave-uniform), one line ahead;
-    // headers and slots are decoded on the scalar unit: byte offsets are pre-scaled on the host
-    // so that a slot costs one s_and, one s_bfe and the sign mask.
+    // Program lines come through the scalar cache (the stream is wave-uniform), ping-pong
+    // buffered one line ahead; only the header is decoded on the scalar unit.
     const uint4* prog4 = reinterpret_cast<const uint4*>(p.prog);
+    auto load_line = [&](FusedLine& L, uint32_t line) {
+        const uint4* lp = prog4 + 8 * size_t(line);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L.q[i] = lp[i];
+    };
+    auto run_line = [&](const FusedLine& L, uint32_t line) {
+        const uint32_t h = L.word(0);
+        const uint32_t kind = h >> 28;
+        if (kind == LINE_MACS) {
+            fused_mac_line<T>(h, L, my, acc);
+        } else if (kind == LINE_MACS_GEN) {
+            fused_mac_general<T>(h, L, my, acc, ctab);
+        } else if (kind == LINE_MISC) {  // element-wise arms: a plain loop over the line in memory
+            const uint32_t cnt = (h >> 15) & 63u;
+            const uint32_t* ops = p.prog + 32 * size_t(line) + 2;
+            for (uint32_t k = 0; k < cnt; ++k) fused_misc<T>(ops[k], my);
+        }
+    };
     for (int ph = 0; ph < ((p.debug_skip & 1) ? 0 : p.n_phases); ++ph) {
         const uint32_t first = p.phase_tab[2 * (ph * FUSED_GROUPS + wave)];
-        const int n_lines = int(p.phase_tab[2 * (ph * FUSED_GROUPS + wave) + 1]);
+        const uint32_t n_lines = p.phase_tab[2 * (ph * FUSED_GROUPS + wave) + 1];
         if (n_lines > 0) {
-            const uint4* lp = prog4 + 2 * first;
-            uint4 a = lp[0], b = lp[1];
-            for (int ln = 0; ln < n_lines; ++ln) {
-                uint4 na = a, nb = b;
-                if (ln + 1 < n_lines) {
-                    na = lp[2 * ln + 2];
-                    nb = lp[2 * ln + 3];
-                }
-                const uint32_t h = a.x;
-                const uint32_t kind = h >> 28;
-                const uint32_t w[7] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                if (kind == LINE_MACS) {
-                    fused_mac_full<T>(h, w, my, acc);
-                } else if (kind == LINE_MACS_GEN) {
-                    fused_mac_counted<T, true>(h, w, my, acc, ctab);
-                } else if (kind == LINE_MISC) {
-                    const uint32_t cnt = (h >> 15) & 7u;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k)
-                        if (uint32_t(k) < cnt) fused_misc<T>(w[k], my);
-                }
-                a = na;
-                b = nb;
+            FusedLine A, B;
+            load_line(A, first);
+            for (uint32_t ln = 0; ln < n_lines; ln += 2) {
+                if (ln + 1 < n_lines) load_line(B, first + ln + 1);
+                run_line(A, first + ln);
+                if (ln + 2 < n_lines) load_line(A, first + ln + 2);
+                if (ln + 1 < n_lines) run_line(B, first + ln + 1);
             }
         }
         __syncthreads();  // the next step reads what every wave wrote

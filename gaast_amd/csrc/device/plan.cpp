@@ -14,6 +14,7 @@
 //       keeps them on the exact kernel).
 #include "plan.hpp"
 
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -483,10 +484,12 @@ bool try_fuse(Plan& plan) {
     // dealt to the workgroup's waves, least-loaded first.  Any split is exact: rows of one
     // Product never read what another row of the same Product writes.
     constexpr int G = uop::GROUPS;
-    std::vector<uint32_t>& prog = f.u32_a;        // 8-word lines, see kernels.hip.hpp
+    constexpr uint32_t LW = 32;                   // words per line
+    std::vector<uint32_t>& prog = f.u32_a;        // 32-word lines, see kernels.hip.hpp
     std::vector<uint32_t>& phase_tab = f.u32_b;   // per (phase, wave): first line, line count
     std::vector<double>& general = f.coeff;
     uint64_t entries = 0;
+    const uint32_t esz = uint32_t(elem);
     auto mop = [](uint32_t code, uint32_t lo, uint32_t mid = 0) { return (code << 28) | (mid << 12) | lo; };
     for (const Step& s : plan.steps) {
         std::vector<std::vector<uint32_t>> glines(G);  // lines of each wave, this phase
@@ -497,12 +500,15 @@ bool try_fuse(Plan& plan) {
                 if (load[size_t(i)] < load[size_t(g)]) g = i;
             return g;
         };
-        auto push_misc = [&](const std::vector<uint32_t>& ops) {  // chunks of 7 ops, dealt round
-            for (size_t i = 0; i < ops.size(); i += 7) {
-                const size_t cnt = std::min<size_t>(7, ops.size() - i);
+        auto push_misc = [&](const std::vector<uint32_t>& ops) {  // chunks of <= 30 ops, dealt round
+            const size_t per = std::max<size_t>(1, std::min<size_t>(30, (ops.size() + G - 1) / G));
+            for (size_t i = 0; i < ops.size(); i += per) {
+                const size_t cnt = std::min(per, ops.size() - i);
                 const int g = least();
-                glines[size_t(g)].push_back((uint32_t(uop::LINE_MISC) << 28) | (uint32_t(cnt) << 15));
-                for (size_t k = 0; k < 7; ++k) glines[size_t(g)].push_back(k < cnt ? ops[i + k] : 0u);
+                std::vector<uint32_t>& out = glines[size_t(g)];
+                out.push_back((uint32_t(uop::LINE_MISC) << 28) | (uint32_t(cnt) << 15));
+                out.push_back(0u);
+                for (size_t k = 0; k < 30; ++k) out.push_back(k < cnt ? ops[i + k] : 0u);
                 load[size_t(g)] += cnt;
             }
         };
@@ -511,7 +517,7 @@ bool try_fuse(Plan& plan) {
         switch (s.kind) {
         case Step::ZERO: {
             const uint32_t len = uint32_t(layout_of(s.res).row_len);
-            for (uint32_t o = 0; o < len; o += 16) misc.push_back(mop(uop::ZERO, rb + o, std::min<uint32_t>(16, len - o)));
+            for (uint32_t o = 0; o < len; o += 8) misc.push_back(mop(uop::ZERO, rb + o, std::min<uint32_t>(8, len - o)));
             push_misc(misc);
             break;
         }
@@ -535,28 +541,28 @@ bool try_fuse(Plan& plan) {
                 const int g = least();
                 std::vector<uint32_t>& out = glines[size_t(g)];
                 load[size_t(g)] += (e1 - e0) + 2;
-                // classify the row: sign-only fresh rows get padded full lines
                 bool row_general = false;
                 for (uint32_t e = e0; e < e1; ++e) row_general |= (s.coeff[e] != 1.0 && s.coeff[e] != -1.0);
-                const bool full_lines = !row_general;
-                const uint32_t esz = uint32_t(elem);
+                // split long rows evenly over their lines (16 entries -> 8 + 8, not 10 + 6)
+                const uint32_t n_l = e1 > e0 ? (e1 - e0 + 9) / 10 : 1;
+                const uint32_t per = e1 > e0 ? (e1 - e0 + n_l - 1) / n_l : 0;
                 uint32_t e = e0;
                 do {  // a row with no entries still stores its (fresh) 0.0
-                    const uint32_t cnt = std::min<uint32_t>(7, e1 - e);
+                    const uint32_t cnt = std::min<uint32_t>(per, e1 - e);
                     uint32_t hdr = dst | (cnt << 15);
                     if (e == e0) hdr |= (1u << 12) | (s.beta ? 0u : (1u << 13));
                     if (e + cnt == e1) hdr |= 1u << 14;
-                    hdr |= uint32_t(full_lines ? uop::LINE_MACS : row_general ? uop::LINE_MACS_GEN : uop::LINE_MACS_CNT) << 28;
-                    out.push_back(hdr);
-                    for (uint32_t k = 0; k < 7; ++k) {
-                        if (k >= cnt) {
-                            out.push_back(0u);
-                            continue;
-                        }
+                    hdr |= uint32_t(row_general ? uop::LINE_MACS_GEN : uop::LINE_MACS) << 28;
+                    const size_t line0 = out.size();
+                    out.resize(line0 + LW, 0u);
+                    out[line0] = hdr;
+                    for (uint32_t k = 0; k < cnt; ++k) {
                         const double c = s.coeff[e + k];
                         const uint32_t lo = lb + (s.u32_c[e + k] & 0xffffu), ro = rrb + (s.u32_c[e + k] >> 16);
                         if (!row_general) {
-                            out.push_back((lo * esz) | ((ro * esz) << 15) | (c == -1.0 ? 0x80000000u : 0u));
+                            out[line0 + 2 + 3 * k] = lo * esz;
+                            out[line0 + 3 + 3 * k] = ro * esz;
+                            out[line0 + 4 + 3 * k] = c == -1.0 ? 0x80000000u : 0u;
                         } else {
                             uint32_t ci;
                             if (c == 1.0) {
@@ -573,7 +579,8 @@ bool try_fuse(Plan& plan) {
                                 }
                                 ci = uint32_t(gi) + 2;
                             }
-                            out.push_back((ci << 24) | (ro << 12) | lo);
+                            out[line0 + 2 + 3 * k] = lo | (ro << 12);
+                            out[line0 + 3 + 3 * k] = ci;
                         }
                         ++entries;
                     }
@@ -585,15 +592,91 @@ bool try_fuse(Plan& plan) {
         default: return false;
         }
         for (int g = 0; g < G; ++g) {
-            phase_tab.push_back(uint32_t(prog.size() / 8));
-            phase_tab.push_back(uint32_t(glines[size_t(g)].size() / 8));
+            phase_tab.push_back(uint32_t(prog.size() / LW));
+            phase_tab.push_back(uint32_t(glines[size_t(g)].size() / LW));
             prog.insert(prog.end(), glines[size_t(g)].begin(), glines[size_t(g)].end());
         }
     }
-    if (prog.size() > (1u << 18)) return false;
-    if (prog.empty()) {
-        prog.push_back(uint32_t(uop::LINE_NOP) << 28);
-        for (int k = 0; k < 7; ++k) prog.push_back(0u);
+    if (prog.size() > (1u << 20)) return false;
+    if (prog.empty()) prog.assign(LW, uint32_t(uop::LINE_NOP) << 28);
+    // ---- the same plan as straight-line HIP source, specialised at program_create through
+    // hiprtc (the reference's README lists code generation from the specialized AST as roadmap).
+    // lane <-> item, every slab element is a local scalar (a register), offsets and signs are
+    // constants, the statements are the reference's in the reference's order; the runtime
+    // compiles it with -ffp-contract=off so that the roundings stay those of eval.rs:82.
+    if (!(plan.flags & GAAST_FLAG_NO_JIT) && entries <= 8192 && slab <= 160) {
+        std::string src;
+        char buf[256];
+        const char* ty = plan.dtype == GAAST_F32 ? "float" : "double";
+        auto lit = [&](double c) {
+            std::snprintf(buf, sizeof(buf), plan.dtype == GAAST_F32 ? "%af" : "%a", plan.dtype == GAAST_F32 ? double(float(c)) : c);
+            return std::string(buf);
+        };
+        auto var = [&](uint32_t i) { return "v" + std::to_string(i); };
+        src += std::string("typedef ") + ty + " T;\nextern \"C\" __global__ __launch_bounds__(256) void gaast_jit(";
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i)
+            src += "const T* __restrict__ in" + std::to_string(i) + ", long long s" + std::to_string(i) + ", ";
+        src += "T* __restrict__ out, long long so, long long batch) {\n";
+        src += "  const long long item = blockIdx.x * 256LL + threadIdx.x;\n  if (item >= batch) return;\n";
+        for (int i = 0; i < slab; ++i) src += "  T " + var(uint32_t(i)) + " = 0;\n";
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const Step::FusedInput& fi = f.fused_inputs[i];
+            const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
+            src += "  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
+            for (int c = 0; c < len; ++c)
+                src += "    " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + r[" : " = r[") + std::to_string(c) + "];\n";
+            src += "  }\n";
+        }
+        for (const Step& s : plan.steps) {
+            const uint32_t rb = uint32_t(base_of(s.res));
+            switch (s.kind) {
+            case Step::ZERO:
+                for (int64_t o = 0; o < layout_of(s.res).row_len; ++o) src += "  " + var(rb + uint32_t(o)) + " = T(0);\n";
+                break;
+            case Step::AXPY:
+                for (uint32_t m : s.u32_a) {
+                    const std::string d = var(rb + (m & 0xffffu));
+                    src += "  " + d + " = " + d + " + " + var(uint32_t(base_of(s.a)) + (m >> 16)) + ";\n";
+                }
+                break;
+            case Step::FLIP:
+                for (uint32_t o : s.u32_a) src += "  " + var(rb + o) + " = -" + var(rb + o) + ";\n";
+                break;
+            case Step::SUNARY: {
+                const std::string d = var(rb + uint32_t(s.sunary_off));
+                if (s.sunary_op == 0)
+                    src += "  " + d + " = T(1) / " + d + ";\n";
+                else
+                    src += "  " + d + (plan.dtype == GAAST_F32 ? " = __builtin_sqrtf(" : " = __builtin_sqrt(") + d + ");\n";
+                break;
+            }
+            case Step::PRODUCT_CSR: {
+                const uint32_t lb = uint32_t(base_of(s.a, s.canon_a)), rrb = uint32_t(base_of(s.b, s.canon_b));
+                for (size_t row = 0; row + 1 < s.u32_a.size(); ++row) {
+                    const std::string d = var(rb + s.u32_b[row]);
+                    src += "  { T acc = " + (s.beta ? d : std::string("T(0)")) + ";\n";
+                    for (uint32_t e = s.u32_a[row]; e < s.u32_a[row + 1]; ++e) {
+                        const std::string prod = "(" + var(lb + (s.u32_c[e] & 0xffffu)) + " * " + var(rrb + (s.u32_c[e] >> 16)) + ")";
+                        const double c = s.coeff[e];
+                        if (c == 1.0)
+                            src += "    acc = acc + " + prod + ";\n";
+                        else if (c == -1.0)
+                            src += "    acc = acc - " + prod + ";\n";
+                        else
+                            src += "    acc = acc + " + prod + " * T(" + lit(c) + ");\n";
+                    }
+                    src += "    " + d + " = acc; }\n";
+                }
+                break;
+            }
+            default: break;
+            }
+        }
+        src += "  T* o = out + item * so;\n";
+        for (int64_t c = 0; c < plan.out_layout.row_len; ++c)
+            src += "  o[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
+        src += "}\n";
+        f.jit_source = std::move(src);
     }
     f.fused_slab = slab;
     f.fused_zero_slot = zero_slot;

@@ -60,6 +60,9 @@ struct Step {
     };
     std::vector<FusedInput> fused_inputs;
     int fused_slab = 0, fused_out_base = 0, fused_zero_slot = 0;
+    std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
+    void* jit_module = nullptr;
+    void* jit_function = nullptr;
     // device copies
     void* d_a = nullptr;
     void* d_b = nullptr;

@@ -1,6 +1,7 @@
 // C ABI of the gfx950 back end (include/gaast_hip.h): device storage of graded rows, program
 // objects (launch plans) and the batched evaluator.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -250,8 +251,66 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
     return GAAST_OK;
 }
 
+// hiprtc specialisation of a fused plan; on any failure the LDS interpreter kernel stays in charge
+bool jit_compile(Step& s, std::string* log) {
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, s.jit_source.c_str(), "gaast_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    const hiprtcResult res = hiprtcCompileProgram(prog, 3, opts);
+    if (res != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        log->assign(n, 0);
+        if (n) hiprtcGetProgramLog(prog, &(*log)[0]);
+        hiprtcDestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
+    if (hipModuleGetFunction(&fn, mod, "gaast_jit") != hipSuccess) {
+        (void)hipModuleUnload(mod);
+        return false;
+    }
+    s.jit_module = mod;
+    s.jit_function = fn;
+    return true;
+}
+
+template <typename T>
+int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound, const Bound& out, int64_t batch) {
+    // argument block: (ptr, stride) per staged input image, then out, out stride, batch
+    std::vector<void*> args;
+    std::vector<const void*> ptrs(s.fused_inputs.size());
+    std::vector<long long> strides(s.fused_inputs.size());
+    for (size_t i = 0; i < s.fused_inputs.size(); ++i) {
+        ptrs[i] = in_bound[size_t(s.fused_inputs[i].slot)].ptr;
+        strides[i] = in_bound[size_t(s.fused_inputs[i].slot)].stride;
+    }
+    for (size_t i = 0; i < s.fused_inputs.size(); ++i) {
+        args.push_back(&ptrs[i]);
+        args.push_back(&strides[i]);
+    }
+    void* optr = out.ptr;
+    long long ostride = out.stride, b = batch;
+    args.push_back(&optr);
+    args.push_back(&ostride);
+    args.push_back(&b);
+    const unsigned blocks = unsigned((batch + 255) / 256);
+    HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, 256, 1, 1, 0, g_stream,
+                                  args.data(), nullptr));
+    (void)plan;
+    return GAAST_OK;
+}
+
 template <typename T>
 int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound, const Bound& out, int64_t batch) {
+    if (s.jit_function) return run_jit<T>(s, plan, in_bound, out, batch);
     FusedArgs<T> p;
     std::memset(&p, 0, sizeof(p));
     p.prog = static_cast<const uint32_t*>(s.d_a);
@@ -357,6 +416,14 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         s.coeff_host = s.kind == Step::FUSED ? s.coeff : std::vector<double>();
         std::vector<uint32_t>().swap(s.u32_c);
         std::vector<double>().swap(s.coeff);
+        if (s.kind == Step::FUSED && !s.jit_source.empty()) {
+            std::string log;
+            if (jit_compile(s, &log))
+                s.name = "ast_jit" + s.name.substr(s.name.find('['));
+            else if (!log.empty())
+                g_err = "hiprtc: " + log;  // informational: the interpreter kernel runs instead
+            std::string().swap(s.jit_source);
+        }
         prog->launch_names.push_back(s.name);
     }
     prog->const_mvs.assign(plan.inputs.size(), nullptr);
@@ -382,9 +449,11 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
 
 int gaast_hip_program_destroy(gaast_hip_program_t prog) {
     if (!prog) return GAAST_OK;
-    for (Step& s : prog->plan.steps)
+    for (Step& s : prog->plan.steps) {
         for (void* p : {s.d_a, s.d_b, s.d_c, s.d_coeff, s.d_i32})
             if (p) (void)hipFree(p);
+        if (s.jit_module) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module));
+    }
     for (gaast_hip_mv_t m : prog->const_mvs) mv_free_impl(m);
     for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
     delete prog;

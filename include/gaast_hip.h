@@ -120,6 +120,7 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_NO_FUSION 0x2u      /* one kernel per eval.rs arm, every operand materialised (A/B testing) */
 #define GAAST_FLAG_EXACT_ORDER 0x4u    /* never use the dense re-ordered product kernel (bit-exact f64 sums) */
 #define GAAST_FLAG_NO_MFMA 0x8u        /* dense products stay on the vector-FMA kernel (A/B testing) */
+#define GAAST_FLAG_NO_JIT 0x10u        /* small programs run on the LDS interpreter kernel, not on hiprtc-specialised code */
 
 typedef struct gaast_program_desc {
     int32_t vec_space_dim;      /* n */

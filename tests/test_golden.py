@@ -34,7 +34,7 @@ def test_oracle_reproduces_golden(name, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [0, 2])   # fused plan; one launch per eval.rs arm
+@pytest.mark.parametrize("flags", [0, 16, 2])   # specialised kernel; LDS interpreter; one launch per eval.rs arm
 @pytest.mark.parametrize("name", sorted(PROGRAMS))
 def test_hip_reproduces_golden(name, flags, golden_dir):
     case = _load(golden_dir)[name]

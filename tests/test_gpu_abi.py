@@ -120,8 +120,9 @@ def test_wrapped_memory_with_row_stride_and_shared_operand():
     assert np.all(big_b.cpu().numpy()[:, N:] == 777.0)
 
 
+@pytest.mark.parametrize("flags,kernel", [(0, "ast_jit"), (ga.FLAG_NO_JIT, "ast_fused")])
 @pytest.mark.parametrize("name,tol", [("cfg1", 1e-5), ("sandwich", 1e-4)])
-def test_f32_extension_of_the_fused_kernel(name, tol):
+def test_f32_extension_of_the_fused_kernel(name, tol, flags, kernel):
     batch = 257
     rng = np.random.default_rng(9)
     if name == "cfg1":
@@ -132,8 +133,8 @@ def test_f32_extension_of_the_fused_kernel(name, tol):
         alg = [1.0, 1.0, 1.0, 1.0, -1.0]
         rows = {0: rows_of(5, [0, 2, 4], batch, rng, np.float32), 1: rows_of(5, [1], batch, rng, np.float32)}
     want, _ = oracle_eval_batch(build, alg, rows, batch)
-    got, _, spec = hip_eval_batch(build, alg, rows, batch, dtype=ga.F32)
-    assert any("ast_fused" in l for l in spec.launches())
+    got, _, spec = hip_eval_batch(build, alg, rows, batch, dtype=ga.F32, flags=flags)
+    assert any(kernel in l for l in spec.launches()), spec.launches()
     assert got.dtype == np.float32 and np.allclose(got, want, rtol=0, atol=tol)
 
 

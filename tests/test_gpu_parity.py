@@ -40,7 +40,14 @@ def _assert_map_equal(h, o):
 # ---- every catalogue expression, one item, f64, exact kernels: bit-exact ----------------------
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_exact_path_bit_exact(name):
+    """default plan for small programs: hiprtc-specialised straight-line kernel (ast_jit)"""
     _assert_map_equal(_hip_value(name, flags=ga.FLAG_EXACT_ORDER), _oracle_value(name))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_interpreter_kernel_bit_exact(name):
+    """same plans on the LDS interpreter kernel (ast_fused), no run-time compilation"""
+    _assert_map_equal(_hip_value(name, flags=ga.FLAG_EXACT_ORDER | ga.FLAG_NO_JIT), _oracle_value(name))
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -64,13 +71,15 @@ def _cfg1(B):
     return (a + b * c).g(2)
 
 
+@pytest.mark.parametrize("flags,kernel", [(0, "ast_jit"), (ga.FLAG_NO_JIT, "ast_fused"), (ga.FLAG_NO_FUSION, "product_csr")])
 @pytest.mark.parametrize("batch", [1, 2, 63, 257, 4096])
-def test_cfg1_batched_bit_exact(batch):
+def test_cfg1_batched_bit_exact(batch, flags, kernel):
     rng = np.random.default_rng(1)
     rows = {s: rows_of(3, full_grades(3), batch, rng) for s in range(3)}
     want, omask = oracle_eval_batch(_cfg1, 3, rows, batch)
-    got, hmask, spec = hip_eval_batch(_cfg1, 3, rows, batch)
+    got, hmask, spec = hip_eval_batch(_cfg1, 3, rows, batch, flags=flags)
     assert hmask == omask == 0b100
+    assert any(kernel in l for l in spec.launches()), spec.launches()
     assert np.array_equal(got, want)
 
 
@@ -81,15 +90,16 @@ def _sandwich(B, g1=False):
     return e.g(1) if g1 else e
 
 
+@pytest.mark.parametrize("flags", [0, ga.FLAG_NO_JIT])
 @pytest.mark.parametrize("g1", [False, True])
 @pytest.mark.parametrize("shared_r", [False, True])
-def test_cfg5_sandwich_batched_bit_exact(g1, shared_r):
+def test_cfg5_sandwich_batched_bit_exact(g1, shared_r, flags):
     batch = 1000
     rng = np.random.default_rng(5)
     rows = {0: rows_of(5, [0, 2, 4], 1 if shared_r else batch, rng), 1: rows_of(5, [1], batch, rng)}
     build = lambda B: _sandwich(B, g1)
     want, omask = oracle_eval_batch(build, CGA, rows, batch)
-    got, hmask, spec = hip_eval_batch(build, CGA, rows, batch)
+    got, hmask, spec = hip_eval_batch(build, CGA, rows, batch, flags=flags)
     assert hmask == omask
     assert np.array_equal(got, want)
     # Q4: the debug-build behaviour of the reference is a panic, reported as a status
