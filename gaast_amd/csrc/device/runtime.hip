@@ -417,6 +417,12 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         std::vector<uint32_t>().swap(s.u32_c);
         std::vector<double>().swap(s.coeff);
         if (s.kind == Step::FUSED && !s.jit_source.empty()) {
+            if (const char* dump = std::getenv("GAAST_DUMP_JIT")) {  // diagnostics: keep the generated source
+                if (FILE* fp = std::fopen(dump, "w")) {
+                    std::fputs(s.jit_source.c_str(), fp);
+                    std::fclose(fp);
+                }
+            }
             std::string log;
             if (jit_compile(s, &log))
                 s.name = "ast_jit" + s.name.substr(s.name.find('['));
