@@ -31,7 +31,9 @@ PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 
 # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 x 1024 +
 # WRITE_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md): (workload, batch) -> bytes
-PMC_TRAFFIC = {("r12", 65536): 2 * 1.04889e6 * 1024 + 1.04858e6 * 1024}
+PMC_TRAFFIC = {("r12", 65536): (2 * 1.04889e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r12_mfma_pmc_counters.csv"),
+               ("r8", 1 << 20): (2 * 1048694.5 * 1024 + 1048861.1 * 1024, "profiles/r01_r8_pmc_counters.csv"),
+               ("cl41", 1 << 22): (2 * 344497.1 * 1024 + 524352.1 * 1024, "profiles/r01_cl41_pmc_counters.csv")}
 
 
 def workload_spec(name):
@@ -208,8 +210,9 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
                     "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
-        roof["traffic"] = PMC_TRAFFIC.get((args.workload, batch))
-        roof["traffic_source"] = "profiles/r01_r12_mfma_pmc_counters.csv (rocprofv3 --pmc, separate passes)" if roof["traffic"] else None
+        pmc = PMC_TRAFFIC.get((args.workload, batch))
+        roof["traffic"] = pmc[0] if pmc else None
+        roof["traffic_source"] = pmc[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if pmc else None
         roof["algorithmic_bytes_per_launch"] = bytes_item * batch
         roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
         roof["kernel_ms"] = kernel_ms
