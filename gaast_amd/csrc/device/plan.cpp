@@ -241,9 +241,30 @@ struct Lowering {
         return store_in_cache(id);  // eval.rs:67-68
     }
 
+    // A host that cannot name the product (the Rust shim: the grades_to_produce closure is opaque,
+    // base_types.rs:60-64) sends GAAST_PROD_EXPLICIT.  A list big enough to matter for the dense
+    // kernels is compared entry by entry with the geometric product's list for the same grade
+    // sets and metric; only an exact match (indices and coefficient bits) is treated as one.
+    bool is_geometric_list(const gaast_node_desc& nd) const {
+        if (nd.product_kind == GAAST_PROD_GEOMETRIC) return true;
+        if (nd.product_kind != GAAST_PROD_EXPLICIT || !nd.comp_muls) return false;
+        const int n = d.vec_space_dim;
+        if (n < 6 || double(nd.n_comp_muls) * 8.0 < double(uint64_t(1) << (2 * n))) return false;
+        const uint64_t lmin = node(nd.child0).minimal_grade_mask, rmin = node(nd.child1).minimal_grade_mask;
+        auto contribs = iter_contribs(nd.minimal_grade_mask, Selection{GAAST_PROD_GEOMETRIC, nullptr, nullptr}, lmin, rmin);
+        if (comp_mul_count(n, contribs) != nd.n_comp_muls) return false;
+        uint64_t e = 0;
+        bool same = true;
+        for_each_comp_mul(bt, d.metric_diag, contribs, [&](const gaast_comp_mul& m) {
+            if (same && std::memcmp(&m, &nd.comp_muls[e], sizeof(gaast_comp_mul)) != 0) same = false;
+            ++e;
+        });
+        return same;
+    }
+
     bool dense_eligible(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
-        if (nd.product_kind != GAAST_PROD_GEOMETRIC) return false;
+        if (!is_geometric_list(nd)) return false;
         const int n = d.vec_space_dim;
         if (n < 6 || n > 13) return false;  // small algebras: the exact kernel is HBM-bound anyway
         if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return false;

@@ -73,7 +73,10 @@ def test_explicit_lists_from_a_foreign_host_are_exact():
     assert np.array_equal(got, want), names
 
 
-def test_explicit_dense_list_without_kind_hint_stays_exact_and_with_hint_goes_dense():
+def test_explicit_dense_list_is_recognised_only_when_it_is_the_geometric_product():
+    """A foreign host cannot name the product (closure opaque): the library compares the list with
+    the geometric product's; an exact match runs on the dense kernel, anything else stays on the
+    exact kernels."""
     n, batch = 6, 17
     rng = np.random.default_rng(6)
     build = lambda B: B.input(0, full_grades(n), n) * B.input(1, full_grades(n), n)
@@ -81,12 +84,21 @@ def test_explicit_dense_list_without_kind_hint_stays_exact_and_with_hint_goes_de
     want, _ = oracle_eval_batch(build, n, rows, batch)
     spec = build(HipBackend()).specialize(n, materialize_limit=0)
     ins = [ga.DeviceMV.from_rows(n, full_grades(n), rows[s]) for s in range(2)]
-    desc, keep = _raw_program(spec)                                   # kind unknown -> exact kernels
-    got, names = _run_raw(desc, ins, batch, n)
-    assert not any("dense" in x for x in names) and np.array_equal(got, want)
-    desc, keep = _raw_program(spec, kind_override=_lib.PROD_GEOMETRIC)  # host vouches: geometric product
+    desc, keep = _raw_program(spec)                                   # kind unknown, list untouched
     got, names = _run_raw(desc, ins, batch, n)
     assert any("dense" in x for x in names) and np.allclose(got, want, rtol=0, atol=1e-12)
+    desc, keep = _raw_program(spec)
+    muls = desc.nodes[2].comp_muls                                    # swap two entries of different outputs:
+    tmp = _lib.CompMul()                                              # same sums, but no longer THE list
+    C.memmove(C.byref(tmp), C.byref(muls[0]), C.sizeof(_lib.CompMul))
+    C.memmove(C.byref(muls[0]), C.byref(muls[1]), C.sizeof(_lib.CompMul))
+    C.memmove(C.byref(muls[1]), C.byref(tmp), C.sizeof(_lib.CompMul))
+    assert (muls[0].result_grade, muls[0].result_index) != (muls[1].result_grade, muls[1].result_index)
+    got, names = _run_raw(desc, ins, batch, n)
+    assert not any("dense" in x for x in names) and np.array_equal(got, want)
+    desc, keep = _raw_program(spec, flags=_lib.FLAG_EXACT_ORDER)      # the host insists on the reference order
+    got, names = _run_raw(desc, ins, batch, n)
+    assert not any("dense" in x for x in names) and np.array_equal(got, want)
 
 
 def test_wrapped_memory_with_row_stride_and_shared_operand():
