@@ -7,10 +7,10 @@ ABI of include/gaast_hip.h (hand-written gfx950 kernels).  There is no CPU evalu
 from ._lib import (F32, F64, FLAG_DEBUG_OVERFLOW, FLAG_EXACT_ORDER, FLAG_NO_FUSION, FLAG_NO_JIT, FLAG_NO_MFMA, GaastError,
                    init_device, lib)
 from .algebra import MetricAlgebra, OrthoEuclidN, n_choose_k
-from .ast import Expr, Input, SpecializedAst, mv
+from .ast import Expr, Input, ProgramImage, SpecializedAst, mv
 from .grade_set import GradeSet
 from .graded import DeviceMV, GradeMapMV, grade_map_mv
 
-__all__ = ["Expr", "Input", "SpecializedAst", "mv", "GradeSet", "GradeMapMV", "grade_map_mv", "DeviceMV",
+__all__ = ["Expr", "Input", "ProgramImage", "SpecializedAst", "mv", "GradeSet", "GradeMapMV", "grade_map_mv", "DeviceMV",
            "MetricAlgebra", "OrthoEuclidN", "n_choose_k", "GaastError", "init_device", "lib",
            "F32", "F64", "FLAG_DEBUG_OVERFLOW", "FLAG_EXACT_ORDER", "FLAG_NO_FUSION", "FLAG_NO_MFMA", "FLAG_NO_JIT"]

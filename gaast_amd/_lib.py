@@ -137,6 +137,10 @@ SIGNATURES = {
     "gaast_spec_node": (_ci, [_vp, _ci, C.POINTER(SpecNodeInfo)]),
     "gaast_spec_comp_muls": (C.POINTER(CompMul), [_vp, _ci]),
     "gaast_spec_program_desc": (_ci, [_vp, _ci, C.c_uint32, C.POINTER(ProgramDesc)]),
+    "gaast_program_serialize": (_sz, [C.POINTER(ProgramDesc), _vp, _sz]),
+    "gaast_program_deserialize": (_vp, [_vp, _sz]),
+    "gaast_program_image_desc": (C.POINTER(ProgramDesc), [_vp]),
+    "gaast_program_image_free": (None, [_vp]),
     "gaast_spec_num_inputs": (_ci, [_vp]),
     "gaast_spec_num_user_inputs": (_ci, [_vp]),
 }

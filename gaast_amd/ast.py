@@ -219,6 +219,14 @@ class SpecializedAst:
         _lib.check(_lib.lib().gaast_spec_program_desc(self._p, self.dtype, self.flags, C.byref(d)))
         return d
 
+    def serialize(self):
+        """The flat program as bytes (program wire format, include/gaast_expr.h)."""
+        d = self.program_desc()
+        n = _lib.lib().gaast_program_serialize(C.byref(d), None, 0)
+        buf = (C.c_ubyte * n)()
+        assert _lib.lib().gaast_program_serialize(C.byref(d), buf, n) == n
+        return bytes(buf)
+
     # -- phase 4 on the device ------------------------------------------------------------------
     def program(self):
         """gaast_hip_program_create for this AST (built once, reused by every eval)."""
@@ -270,3 +278,47 @@ class SpecializedAst:
         out = self.eval_batch((), 1)
         _lib.check(_lib.lib().gaast_hip_synchronize())
         return out.item(0)
+
+
+class ProgramImage:
+    """A program decoded from its wire format; evaluates like a SpecializedAst."""
+
+    def __init__(self, data: bytes):
+        self._buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        self._img = C.c_void_p(_lib.lib().gaast_program_deserialize(self._buf, len(data)))
+        if not self._img:
+            raise _lib.GaastError(1, "malformed program image")
+        self.desc = _lib.lib().gaast_program_image_desc(self._img).contents
+        self._prog = None
+
+    def __del__(self):
+        try:
+            if self._prog:
+                _lib.lib().gaast_hip_program_destroy(self._prog)
+            _lib.lib().gaast_program_image_free(self._img)
+        except Exception:
+            pass
+
+    def eval_batch(self, inputs, batch):
+        L = _lib.lib()
+        _lib.init_device()
+        if self._prog is None:
+            h = C.c_void_p()
+            _lib.check(L.gaast_hip_program_create(C.byref(self.desc), C.byref(h)))
+            self._prog = h
+        mask, rl = C.c_uint64(), C.c_int64()
+        _lib.check(L.gaast_hip_program_output_info(self._prog, C.byref(mask), C.byref(rl)))
+        handles = (C.c_void_p * max(1, self.desc.n_inputs))()
+        keep = []
+        for slot, x in enumerate(inputs):
+            if x is None:
+                continue
+            if not isinstance(x, DeviceMV):
+                ind = self.desc.inputs[slot]
+                x = DeviceMV.from_rows(ind.storage_dim, GradeSet(ind.grade_mask), x, self.desc.dtype)
+            keep.append(x)
+            handles[slot] = x._h
+        out = DeviceMV.alloc(self.desc.nodes[self.desc.root].vec_space_dim, GradeSet(mask.value), batch, self.desc.dtype)
+        _lib.check(L.gaast_hip_eval(self._prog, handles, self.desc.n_inputs, batch, out._h))
+        out._keep_inputs = keep
+        return out

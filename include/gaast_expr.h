@@ -110,6 +110,19 @@ const gaast_comp_mul *gaast_spec_comp_muls(gaast_spec_t s, int idx);
 /* The flat program for gaast_hip_program_create(); pointers stay valid until gaast_spec_free.
  * Embedded constants are appended after the caller's input slots. */
 int gaast_spec_program_desc(gaast_spec_t s, int dtype, uint32_t flags, gaast_program_desc *out);
+/* ---- program wire format ------------------------------------------------------
+ * The reference's SpecializedAst cannot be stored (closures and pointer ids, base_types.rs:60-64,
+ * 92-96); the flat program can.  Layout (little endian): "GAASTPRG", u32 version = 1, then the
+ * fields of gaast_program_desc in order, every array length-prefixed; comp-mul lists as 32-byte
+ * gaast_comp_mul records.  gaast_program_serialize returns the number of bytes needed / written
+ * (call with buf = NULL to size); gaast_program_deserialize returns a handle that owns the
+ * decoded arrays, or NULL on a malformed image. */
+typedef struct gaast_program_image_s *gaast_program_image_t;
+size_t gaast_program_serialize(const gaast_program_desc *desc, void *buf, size_t cap);
+gaast_program_image_t gaast_program_deserialize(const void *buf, size_t len);
+const gaast_program_desc *gaast_program_image_desc(gaast_program_image_t img);
+void gaast_program_image_free(gaast_program_image_t img);
+
 /* number of input slots the program expects (caller slots + embedded constants) */
 int gaast_spec_num_inputs(gaast_spec_t s);
 int gaast_spec_num_user_inputs(gaast_spec_t s);
