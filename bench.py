@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r8|cl41]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r8|cl41]
 
 A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
 multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
@@ -45,6 +45,15 @@ def workload_spec(name):
         return dict(n=n, metric=[1.0] * n, dtype=ga.F32, dtname="f32", inputs=[full, full],
                     build=lambda a, b: a * b, entries=4 ** n, default_batch=65536,
                     label="R^12 full MV x MV geometric product, f32 (BASELINE configs[2])")
+    if name == "r12s":
+        # same products through the opt-in matrix-representation kernel (GAAST_FLAG_SPINOR_GEMM): not the
+        # reference's summation order, so it is a separate workload and never the default line
+        n = 12
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F32, dtname="f32", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=65536, flags=ga.FLAG_SPINOR_GEMM,
+                    flops_item=2 * 4 * 64 ** 3 + 3 * 128 * 64 * 6,
+                    label="R^12 full MV x MV geometric product, f32, opt-in 64x64 complex matrix representation")
     if name == "r8":
         n = 8
         full = list(range(n + 1))
@@ -136,7 +145,7 @@ def main():
     # one SpecializedAst (phases 1-3 on the host, once), one device program
     exprs = [ga.mv(ga.Input(s, g, n)) for s, g in enumerate(wl["inputs"])]
     t0 = time.time()
-    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype)
+    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=wl.get("flags", 0))
     spec.program()
     t_spec = time.time() - t0
     out_mask, out_len = spec.output_info()
@@ -196,9 +205,10 @@ def main():
         sz = 4 if dtype == ga.F32 else 8
         in_len = sum(t.shape[1] for t in in_t)
         bytes_item = (in_len + out_len) * sz          # every input/output component touched once
-        flops_item = 2 * wl["entries"]                # one multiply + one add per comp-mul entry
+        # one multiply + one add per comp-mul entry (the matrix-representation kernel: what it executes)
+        flops_item = wl.get("flops_item", 2 * wl["entries"])
         launches = spec.launches()
-        dense = any("product_dense" in l for l in launches)
+        dense = any("product_dense" in l or "product_spinor" in l for l in launches)
         peak_tf = PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS
         ach_tf = flops_item * batch / (kernel_ms * 1e-3) * 1e-12
         ach_gb = bytes_item * batch / (kernel_ms * 1e-3) * 1e-9

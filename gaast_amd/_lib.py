@@ -21,7 +21,7 @@ F64, F32 = 0, 1
 OP_NAMES = ["GradedObj", "Addition", "Product", "Negation", "Exponential", "Logarithm",
             "GradeProjection", "Reverse", "GradeInvolution", "ScalarInversion", "ScalarSqrt"]
 PROD_EXPLICIT, PROD_GEOMETRIC, PROD_OUTER, PROD_INNER, PROD_LCONTRACT, PROD_RCONTRACT = -1, 0, 1, 2, 3, 4
-FLAG_DEBUG_OVERFLOW, FLAG_NO_FUSION, FLAG_EXACT_ORDER, FLAG_NO_MFMA, FLAG_NO_JIT = 1, 2, 4, 8, 16
+FLAG_DEBUG_OVERFLOW, FLAG_NO_FUSION, FLAG_EXACT_ORDER, FLAG_NO_MFMA, FLAG_NO_JIT, FLAG_SPINOR_GEMM = 1, 2, 4, 8, 16, 32
 
 
 class GaastError(RuntimeError):

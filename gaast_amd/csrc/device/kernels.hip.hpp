@@ -872,4 +872,198 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// OPT-IN fast path (GAAST_FLAG_SPINOR_GEMM): the geometric product of a non-degenerate algebra
+// with n = 12 through its matrix representation -- 16x fewer multiply-adds than the bilinear
+// contraction, all of them on the matrix cores.  NOT the reference's algorithm: same result in
+// exact arithmetic, different roundings (norm-wise error bound), so it is never
+// selected unless the host asks for it.
+//
+// Cl(p,q), p+q = 12, over the complex numbers is the algebra of 64 x 64 matrices.  With the
+// Jordan-Wigner generators gamma_{2j} = Z..Z X_j, gamma_{2j+1} = Z..Z Y_j (times i for the vectors
+// that square to -1), a blade e_S is i^k(S) X^x(S) Z^z(S), a Pauli string; S -> (x, z) is a
+// bijection onto 6-bit pairs.  (X^x Z^z)[c^x][c] = (-1)^|c & z|, so for the multivector A
+//     M_A[c ^ x][c] = sum_z (-1)^|c & z| * i^k(x,z) A_{S(x,z)}       -- a Walsh-Hadamard transform
+// over z of row x of the re-indexed components; the product is C = M_A M_B (complex 64^3
+// GEMM = 4 real ones = 512 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
+// transform of the skewed diagonals of C gives the components back.
+//
+// Workgroup = one item, 256 threads.  LDS: four 64 x 65 f32 planes (A re/im, B re/im; the +1
+// column makes both the row-wise and the XOR-skewed column-wise accesses conflict-free).
+//   1. scatter the graded rows into W[x][z] (table: row offset | plane position | k | negate)
+//   2. 256 threads = 256 row transforms (2 operands x re/im x 64 rows), 64 values in registers;
+//      A rows are written back in place (S_A[x][c] = M_A[c^x][c]), B rows XOR-permuted
+//      (S_B[x][r] = M_B[r][r^x]) so that both MFMA operand gathers hit 32 distinct banks
+//   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair 4 ds_read_b32 and 4 MFMAs
+//   4. C tiles go back to LDS skewed, 128 row transforms, and each transformed value is the
+//      component of one blade (real part for even k, imaginary for odd k).
+// ------------------------------------------------------------------------------------------
+struct SpinorArgs {
+    const float* left;
+    const float* right;
+    float* out;
+    int64_t left_stride, right_stride, out_stride;
+    const uint32_t* left_map;   // per loaded component: row offset [15:0] | x*65+z [28:16] | k [30:29] | negate [31]
+    const uint32_t* right_map;
+    int left_count, right_count;
+    int left_full, right_full;
+    const int32_t* out_map;     // per (x*64 + z): out row offset | k << 16, or -1
+    int canon_left, canon_right;
+    int beta;
+    int64_t batch;
+};
+
+__device__ __forceinline__ void wht64(float (&v)[64]) {
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int hlf = 1 << st;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if ((i & hlf) == 0) {
+                const float a = v[i], b = v[i | hlf];
+                v[i] = a + b;
+                v[i | hlf] = a - b;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gp_spinor12(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int D = 64, LD = 65, P = D * LD;  // plane = 64 rows of 65
+    const int tid = threadIdx.x;
+    const int64_t item = blockIdx.x;
+
+    // ---- 1. graded rows -> W[x][z], split into real / imaginary planes by the phase i^k ----
+    if (!p.left_full || !p.right_full) {
+        for (int i = tid; i < 4 * P; i += 256) smem[i] = 0.f;
+        __syncthreads();
+    }
+    {
+        const float* lrow = p.left + item * p.left_stride;
+        const float* rrow = p.right + item * p.right_stride;
+        for (int j0 = tid; j0 < 4096; j0 += 256 * 4) {
+            uint32_t ml[4], mr[4];
+            float vl[4], vr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                ml[u] = j < p.left_count ? p.left_map[j] : 0u;
+                mr[u] = j < p.right_count ? p.right_map[j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                vl[u] = j < p.left_count ? lrow[ml[u] & 0xffffu] : 0.f;
+                vr[u] = j < p.right_count ? rrow[mr[u] & 0xffffu] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                if (j < p.left_count) {
+                    float a = vl[u];
+                    if (p.canon_left) a = 0.f + a;
+                    const uint32_t k = (ml[u] >> 29) & 3u;
+                    if (((ml[u] >> 31) ^ (k >> 1)) & 1u) a = -a;   // folded unary sign, and i^2 = -1
+                    const int pos = int((ml[u] >> 16) & 0x1fffu);
+                    smem[pos] = (k & 1u) ? 0.f : a;
+                    smem[P + pos] = (k & 1u) ? a : 0.f;
+                }
+                if (j < p.right_count) {
+                    float b = vr[u];
+                    if (p.canon_right) b = 0.f + b;
+                    const uint32_t k = (mr[u] >> 29) & 3u;
+                    if (((mr[u] >> 31) ^ (k >> 1)) & 1u) b = -b;
+                    const int pos = int((mr[u] >> 16) & 0x1fffu);
+                    smem[2 * P + pos] = (k & 1u) ? 0.f : b;
+                    smem[3 * P + pos] = (k & 1u) ? b : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. Walsh-Hadamard transform of every row: thread = (operand, plane, x) ----
+    {
+        const int x = tid & 63;
+        float* row = smem + (tid >> 6) * P + x * LD;
+        float v[64];
+#pragma unroll
+        for (int z = 0; z < 64; ++z) v[z] = row[z];
+        wht64(v);
+        if (tid < 128) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) row[c] = v[c];          // S_A[x][c] = M_A[c^x][c]
+        } else {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) row[c ^ x] = v[c];      // S_B[x][r] = M_B[r][r^x], r = c ^ x
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. complex 64 x 64 x 64 product on the matrix cores ----
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
+    float16v cre, cim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        cre[r] = 0.f;
+        cim[r] = 0.f;
+    }
+    {
+        const float* Are = smem;
+        const float* Aim = smem + P;
+        const float* Bre = smem + 2 * P;
+        const float* Bim = smem + 3 * P;
+        const int ra = r0 + i, cb = c0 + i;
+#pragma unroll 4
+        for (int s2 = 0; s2 < 32; ++s2) {
+            const int k = 2 * s2 + h;
+            const int ia = (ra ^ k) * LD + k;   // M_A[ra][k] = S_A[ra ^ k][k]
+            const int ib = (k ^ cb) * LD + k;   // M_B[k][cb] = S_B[k ^ cb][k]
+            const float are = Are[ia], aim = Aim[ia], bre = Bre[ib], bim = Bim[ib];
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, cre, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-aim, bim, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bim, cim, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bre, cim, 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done reading A and B
+
+    // ---- 4. C back to LDS, skewed: S_C[r ^ c][c] = C[r][c] (reusing the A planes) ----
+    {
+        const int c = c0 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            smem[(rr ^ c) * LD + c] = cre[r];
+            smem[P + (rr ^ c) * LD + c] = cim[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int x = tid & 63, plane = tid >> 6;
+        const float* row = smem + plane * P + x * LD;
+        float v[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) v[c] = row[c];
+        wht64(v);
+        // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3
+        float* orow = p.out + item * p.out_stride;
+        const int32_t* om = p.out_map + x * 64;
+#pragma unroll
+        for (int z = 0; z < 64; ++z) {
+            const int32_t e = om[z];
+            if (e >= 0 && ((e >> 16) & 1) == plane) {
+                float val = v[z] * (1.0f / 64.0f);
+                if ((e >> 17) & 1) val = -val;
+                const int off = e & 0xffff;
+                orow[off] = p.beta ? orow[off] + val : val;
+            }
+        }
+    }
+}
+
 }  // namespace gaast

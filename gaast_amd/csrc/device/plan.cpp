@@ -277,6 +277,36 @@ struct Lowering {
         return double(nd.n_comp_muls) * 8.0 >= full;  // the tiled kernel always does 4^n multiply-adds
     }
 
+    // opt-in matrix-representation kernel (k_gp_spinor12): f32, n = 12, every vector squares to +-1
+    bool spinor_eligible(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r) const {
+        if (!(plan.flags & GAAST_FLAG_SPINOR_GEMM)) return false;
+        if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
+        if (plan.dtype != GAAST_F32 || d.vec_space_dim != 12) return false;
+        if (layout(res).dim != 12 || layout(l).dim != 12 || layout(r).dim != 12) return false;
+        for (int i = 0; i < 12; ++i)
+            if (d.metric_diag[i] != 1.0 && d.metric_diag[i] != -1.0) return false;
+        if (!is_geometric_list(nd)) return false;
+        return double(nd.n_comp_muls) * 8.0 >= double(uint64_t(1) << 24);
+    }
+
+    // blade -> Pauli string i^k X^x Z^z under the Jordan-Wigner generators (kernels.hip.hpp)
+    void pauli_string(uint32_t blade, uint32_t* x, uint32_t* z, uint32_t* k) const {
+        uint32_t px = 0, pz = 0, pk = 0;
+        for (int v = 0; v < d.vec_space_dim; ++v) {
+            if (!((blade >> v) & 1u)) continue;
+            const int j = v >> 1;
+            const uint32_t gx = 1u << j;
+            const uint32_t gz = (v & 1) ? (1u << (j + 1)) - 1u : (1u << j) - 1u;
+            const uint32_t gk = uint32_t(v & 1) + (d.metric_diag[v] < 0.0 ? 1u : 0u);
+            pk = (pk + gk + 2u * uint32_t(__builtin_popcount(pz & gx))) & 3u;
+            px ^= gx;
+            pz ^= gz;
+        }
+        *x = px;
+        *z = pz;
+        *k = pk;
+    }
+
     void lower_product(BufRef res, int id) {  // eval.rs:61-86
         const gaast_node_desc& nd = node(id);
         int canon_l = 0, canon_r = 0;
@@ -299,6 +329,48 @@ struct Lowering {
         auto fr = fresh.find(key(res));
         const bool is_fresh = fr != fresh.end() && !(plan.flags & GAAST_FLAG_NO_FUSION);
 
+        if (spinor_eligible(nd, res, l, r)) {
+            if ((omin & lr.mask) != omin) {
+                fail(GAAST_ERR_MISSING_GRADE, "product result grade absent from result buffer");
+                return;
+            }
+            const bool beta0 = is_fresh && (lr.mask & ~omin) == 0;
+            if (beta0) removed[size_t(fr->second)] = 1;
+            Step& s = emit(Step::PRODUCT_DENSE, res, "product_spinor_gemm[gp n=12]");
+            s.a = l;
+            s.b = r;
+            s.canon_a = canon_l;
+            s.canon_b = canon_r;
+            s.beta = beta0 ? 0 : 1;
+            s.n_entries = nd.n_comp_muls;
+            s.use_spinor = 1;
+            const int n = 12;
+            // entry: row offset | (x*65 + z) << 16 | k << 29 | (negate while staging) << 31
+            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, std::vector<uint32_t>& map, int* full) {
+                for (int k = 0; k <= n; ++k) {
+                    if (!((want >> k) & 1ULL)) continue;
+                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
+                    for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
+                        uint32_t px, pz, pk;
+                        pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
+                        map.push_back(uint32_t(lay.offset(k) + i) | ((px * 65u + pz) << 16) | (pk << 29) | sgn);
+                    }
+                }
+                *full = map.size() == (size_t(1) << n);
+            };
+            build_map(ll, lmin & ll.mask, flip_l, s.u32_a, &s.left_full);
+            build_map(lrr, rmin & lrr.mask, flip_r, s.u32_b, &s.right_full);
+            s.i32_a.assign(size_t(1) << n, -1);
+            for (uint32_t m = 0; m < (1u << n); ++m) {
+                const int g = __builtin_popcount(m);
+                if (!((omin >> g) & 1ULL)) continue;
+                uint32_t px, pz, pk;
+                pauli_string(m, &px, &pz, &pk);
+                s.i32_a[px * 64u + pz] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (pk << 16));
+            }
+            touch(res);
+            return;
+        }
         if (dense_eligible(nd, res, l, r)) {
             if ((omin & lr.mask) != omin) {
                 fail(GAAST_ERR_MISSING_GRADE, "product result grade absent from result buffer");

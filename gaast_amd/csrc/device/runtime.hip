@@ -180,6 +180,34 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
     }
     case Step::FUSED: return GAAST_OK;  // launched by run_fused (needs every bound buffer)
     case Step::PRODUCT_DENSE: {
+        if (s.use_spinor) {
+            if constexpr (std::is_same<T, float>::value) {
+                SpinorArgs q;
+                q.left = static_cast<const float*>(a.ptr);
+                q.right = static_cast<const float*>(b.ptr);
+                q.out = static_cast<float*>(res.ptr);
+                q.left_stride = a.stride;
+                q.right_stride = b.stride;
+                q.out_stride = res.stride;
+                q.left_map = static_cast<const uint32_t*>(s.d_a);
+                q.right_map = static_cast<const uint32_t*>(s.d_b);
+                q.left_count = int(s.u32_a.size());
+                q.right_count = int(s.u32_b.size());
+                q.left_full = s.left_full;
+                q.right_full = s.right_full;
+                q.out_map = static_cast<const int32_t*>(s.d_i32);
+                q.canon_left = s.canon_a;
+                q.canon_right = s.canon_b;
+                q.beta = s.beta;
+                q.batch = batch;
+                const size_t lds = size_t(4) * 64 * 65 * sizeof(float);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_spinor12),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                hipLaunchKernelGGL(k_gp_spinor12, dim3(unsigned(batch)), dim3(256), lds, g_stream, q);
+                break;
+            }
+            return set_err(GAAST_ERR_INVALID_PROGRAM, "matrix-representation product is f32 only");
+        }
         DenseArgs<T> p;
         p.left = static_cast<const T*>(a.ptr);
         p.right = static_cast<const T*>(b.ptr);

@@ -225,6 +225,83 @@ def test_dense_n12_basis_blades_exact():
         assert np.array_equal(got[i], want)
 
 
+# ---- opt-in matrix-representation product (GAAST_FLAG_SPINOR_GEMM) ------------------------------
+# Not the reference's summation: equal in exact arithmetic, so the check is the norm-wise bound the
+# header states, |err_S| <= 64 eps |A|_2 |B|_2, against the float64 bitmask convolution.
+SPINOR_METRICS = [[1.0] * 12, [-1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, -1.0]]
+
+
+@pytest.mark.parametrize("metric", SPINOR_METRICS)
+def test_spinor_gemm_n12_against_bitmask_convolution(metric):
+    n, batch = 12, 4
+    rng = np.random.default_rng(21)
+    rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    for i in range(batch):
+        A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
+        want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
+        bound = 64 * 2.0 ** -23 * np.linalg.norm(rows[0][i].astype(np.float64)) * np.linalg.norm(rows[1][i].astype(np.float64))
+        err = np.abs(got[i].astype(np.float64) - want).max()
+        assert err <= bound, (err, bound)
+
+
+@pytest.mark.parametrize("metric", SPINOR_METRICS)
+def test_spinor_gemm_basis_blades_exact(metric):
+    """One-hot operands: every intermediate is a small integer, so the signs, the phases i^k and the
+    blade <-> Pauli-string tables are checked exactly, for all 4096 x (a sample of) 4096 pairs."""
+    n = 12
+    rng = np.random.default_rng(22)
+    batch = 512
+    a_idx, b_idx = rng.integers(0, 4096, batch), rng.integers(0, 4096, batch)
+    a_idx[:64] = np.arange(64) * 64 + 1
+    ra, rb = np.zeros((batch, 4096), np.float32), np.zeros((batch, 4096), np.float32)
+    ra[np.arange(batch), a_idx] = 1.0
+    rb[np.arange(batch), b_idx] = 1.0
+    got, _, spec = hip_eval_batch(_gp(n), metric, {0: ra, 1: rb}, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches())
+    from helpers import blades_in_row_order
+    blades = blades_in_row_order(n, full_grades(n))
+    pos_of = np.zeros(4096, dtype=np.int64)
+    pos_of[blades] = np.arange(4096)
+    for i in range(batch):
+        a, b = int(blades[a_idx[i]]), int(blades[b_idx[i]])
+        A = np.zeros(4096); A[a] = 1.0
+        Bb = np.zeros(4096); Bb[b] = 1.0
+        want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb)).astype(np.float32)
+        assert np.array_equal(got[i], want), (i, a, b)
+
+
+def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand():
+    """rotor-like even operand (shared by all items), reversed on the fly, odd result only."""
+    n, batch = 12, 3
+    rng = np.random.default_rng(23)
+    even = [k for k in range(n + 1) if k % 2 == 0]
+    odd = [k for k in range(n + 1) if k % 2 == 1]
+    build = lambda B: (B.input(0, even, n).rev() * B.input(1, full_grades(n), n)).gselect(odd)
+    rows = {0: rows_of(n, even, 1, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    spec = build(HipBackend()).specialize(n, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    out = spec.eval_batch([rows[0], rows[1]], batch)
+    got = out.download_rows()
+    assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    A = row_to_bits(n, even, rows[0][0].astype(np.float64))
+    for m in range(4096):
+        k = bin(m).count("1")
+        if (k * (k - 1) // 2) % 2:
+            A[m] = -A[m]
+    for i in range(batch):
+        full = gp_bits(n, [1.0] * n, A, row_to_bits(n, full_grades(n), rows[1][i].astype(np.float64)))
+        want = bits_to_row(n, odd, full)
+        bound = 64 * 2.0 ** -23 * np.linalg.norm(A) * np.linalg.norm(rows[1][i].astype(np.float64))
+        assert np.abs(got[i].astype(np.float64) - want).max() <= bound
+
+
+@pytest.mark.parametrize("name", ["cfg1_r3", "cfg5_sandwich", "r6_gp_full", "weird_metric_gp"])
+def test_spinor_flag_is_ignored_where_it_does_not_apply(name):
+    """f64, other dimensions, degenerate metrics: the flag changes nothing."""
+    _assert_map_equal(_hip_value(name, flags=ga.FLAG_SPINOR_GEMM), _hip_value(name))
+
+
 # ---- storage, errors, edges ------------------------------------------------------------------
 def test_upload_download_per_grade_roundtrip():
     rng = np.random.default_rng(0)
