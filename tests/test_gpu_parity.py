@@ -264,11 +264,12 @@ def test_spinor_gemm_basis_blades_exact(metric):
     blades = blades_in_row_order(n, full_grades(n))
     pos_of = np.zeros(4096, dtype=np.int64)
     pos_of[blades] = np.arange(4096)
+    alg = ga.MetricAlgebra(metric)
     for i in range(batch):
         a, b = int(blades[a_idx[i]]), int(blades[b_idx[i]])
-        A = np.zeros(4096); A[a] = 1.0
-        Bb = np.zeros(4096); Bb[b] = 1.0
-        want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb)).astype(np.float32)
+        res, coeff = alg.ortho_basis_blades_gp(a, b)       # algebra.rs:73-83 (host mirror, pinned by the CPU suite)
+        want = np.zeros(4096, np.float32)
+        want[pos_of[res]] = coeff
         assert np.array_equal(got[i], want), (i, a, b)
 
 
