@@ -903,22 +903,25 @@ struct SpinorArgs {
     const float* right;
     float* out;
     int64_t left_stride, right_stride, out_stride;
-    const uint32_t* left_map;   // per loaded component: row offset [15:0] | x*65+z [28:16] | k [30:29] | negate [31]
-    const uint32_t* right_map;
-    int left_count, right_count;
+    // 4096 entries each, indexed by ROW OFFSET: x*65+z [12:0] | k [14:13] | negate [15];
+    // 0xffff = offset beyond the row / grade not wanted
+    const uint16_t* left_map;
+    const uint16_t* right_map;
+    const uint16_t* out_map;
+    int left_len, right_len;
     int left_full, right_full;
-    const int32_t* out_map;     // per (x*64 + z): out row offset | k << 16, or -1
     int canon_left, canon_right;
     int beta;
     int64_t batch;
+    int debug_skip;
 };
 
-__device__ __forceinline__ void wht64(float (&v)[64]) {
+template <int N>
+__device__ __forceinline__ void wht(float (&v)[N]) {
 #pragma unroll
-    for (int st = 0; st < 6; ++st) {
-        const int hlf = 1 << st;
+    for (int hlf = 1; hlf < N; hlf <<= 1) {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < N; ++i) {
             if ((i & hlf) == 0) {
                 const float a = v[i], b = v[i | hlf];
                 v[i] = a + b;
@@ -928,141 +931,176 @@ __device__ __forceinline__ void wht64(float (&v)[64]) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_gp_spinor12(SpinorArgs p) {
+// Persistent workgroups (grid = resident blocks): the three tables live in registers for the
+// whole launch and the operands of the NEXT item are fetched while the matrix cores work on the
+// current one, so no phase waits on HBM latency.
+__global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int D = 64, LD = 65, P = D * LD;  // plane = 64 rows of 65
+    constexpr uint32_t NONE = 0xffffu;
     const int tid = threadIdx.x;
-    const int64_t item = blockIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
 
-    // ---- 1. graded rows -> W[x][z], split into real / imaginary planes by the phase i^k ----
-    if (!p.left_full || !p.right_full) {
-        for (int i = tid; i < 4 * P; i += 256) smem[i] = 0.f;
-        __syncthreads();
+    // entry e = tid + 256 u; two 16-bit entries per register (u = 2w, 2w+1)
+    uint32_t lm[8], rm[8], om[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
+        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
+        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
     }
-    {
+    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (m[u >> 1] >> ((u & 1) * 16)) & 0xffffu; };
+    float va[16], vb[16];
+    auto fetch = [&](int64_t item) {
         const float* lrow = p.left + item * p.left_stride;
         const float* rrow = p.right + item * p.right_stride;
-        for (int j0 = tid; j0 < 4096; j0 += 256 * 4) {
-            uint32_t ml[4], mr[4];
-            float vl[4], vr[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
-                ml[u] = j < p.left_count ? p.left_map[j] : 0u;
-                mr[u] = j < p.right_count ? p.right_map[j] : 0u;
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            va[u] = e < p.left_len ? lrow[e] : 0.f;
+            vb[u] = e < p.right_len ? rrow[e] : 0.f;
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+    // Two workgroups share a CU.  Started together they run in lockstep (both in the GEMM, then both
+    // in the transforms) and the matrix cores idle two thirds of the time; the one whose LDS block
+    // does not start at 0 waits about half an item so that its GEMM overlaps the other's transforms.
+    if (!(p.debug_skip & 32)) {
+        const uint32_t lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);  // HW_REG_LDS_ALLOC, LDS_BASE in the low bits
+        if ((lds_alloc & 0xfffu) != 0) {
+            const int naps = (p.debug_skip >> 8) ? (p.debug_skip >> 8) : 3;
+            for (int d = 0; d < naps; ++d) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+
+    for (; item < p.batch; item += gridDim.x) {
+        // keep the packed tables packed: without this the decoded fields of all 48 entries are hoisted
+        // out of the loop and the kernel spills
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
-                vl[u] = j < p.left_count ? lrow[ml[u] & 0xffffu] : 0.f;
-                vr[u] = j < p.right_count ? rrow[mr[u] & 0xffffu] : 0.f;
-            }
+        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        // ---- 1. graded rows -> W[x][z], split into real / imaginary planes by the phase i^k ----
+        if (!p.left_full || !p.right_full) {
+            for (int i = tid; i < 4 * P; i += 256) smem[i] = 0.f;
+            __syncthreads();
+        }
+        if (!(p.debug_skip & 1)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
-                if (j < p.left_count) {
-                    float a = vl[u];
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t el = entry(lm, u), er = entry(rm, u);
+                if (el != NONE) {
+                    float a = va[u];
                     if (p.canon_left) a = 0.f + a;
-                    const uint32_t k = (ml[u] >> 29) & 3u;
-                    if (((ml[u] >> 31) ^ (k >> 1)) & 1u) a = -a;   // folded unary sign, and i^2 = -1
-                    const int pos = int((ml[u] >> 16) & 0x1fffu);
+                    const uint32_t k = (el >> 13) & 3u;
+                    if (((el >> 15) ^ (k >> 1)) & 1u) a = -a;   // folded unary sign, and i^2 = -1
+                    const int pos = int(el & 0x1fffu);
                     smem[pos] = (k & 1u) ? 0.f : a;
                     smem[P + pos] = (k & 1u) ? a : 0.f;
                 }
-                if (j < p.right_count) {
-                    float b = vr[u];
+                if (er != NONE) {
+                    float b = vb[u];
                     if (p.canon_right) b = 0.f + b;
-                    const uint32_t k = (mr[u] >> 29) & 3u;
-                    if (((mr[u] >> 31) ^ (k >> 1)) & 1u) b = -b;
-                    const int pos = int((mr[u] >> 16) & 0x1fffu);
+                    const uint32_t k = (er >> 13) & 3u;
+                    if (((er >> 15) ^ (k >> 1)) & 1u) b = -b;
+                    const int pos = int(er & 0x1fffu);
                     smem[2 * P + pos] = (k & 1u) ? 0.f : b;
                     smem[3 * P + pos] = (k & 1u) ? b : 0.f;
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        // operands of the next item: in flight during the transforms and the GEMM
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
 
-    // ---- 2. Walsh-Hadamard transform of every row: thread = (operand, plane, x) ----
-    {
-        const int x = tid & 63;
-        float* row = smem + (tid >> 6) * P + x * LD;
-        float v[64];
+        // ---- 2. Walsh-Hadamard transform of every row: thread = (operand, plane, x) ----
+        if (!(p.debug_skip & 2)) {
+            float* row = smem + (tid >> 6) * P + (tid & 63) * LD;
+            float v[64];
 #pragma unroll
-        for (int z = 0; z < 64; ++z) v[z] = row[z];
-        wht64(v);
-        if (tid < 128) {
+            for (int z = 0; z < 64; ++z) v[z] = row[z];
+            wht<64>(v);
+            // S_A[x][c] = M_A[c^x][c] = T_x[c].  S_B[x][r] = M_B[r][r^x] = T_x[r^x]: a shift of the
+            // transform's index by x is a sign (-1)^|x&z| on its input, which the right operand's table
+            // already carries, so both operands are written back in place.
 #pragma unroll
-            for (int c = 0; c < 64; ++c) row[c] = v[c];          // S_A[x][c] = M_A[c^x][c]
-        } else {
-#pragma unroll
-            for (int c = 0; c < 64; ++c) row[c ^ x] = v[c];      // S_B[x][r] = M_B[r][r^x], r = c ^ x
+            for (int c = 0; c < 64; ++c) row[c] = v[c];
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- 3. complex 64 x 64 x 64 product on the matrix cores ----
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i = lane & 31, h = lane >> 5;
-    const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
-    float16v cre, cim;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        cre[r] = 0.f;
-        cim[r] = 0.f;
-    }
-    {
-        const float* Are = smem;
-        const float* Aim = smem + P;
-        const float* Bre = smem + 2 * P;
-        const float* Bim = smem + 3 * P;
-        const int ra = r0 + i, cb = c0 + i;
-#pragma unroll 4
-        for (int s2 = 0; s2 < 32; ++s2) {
-            const int k = 2 * s2 + h;
-            const int ia = (ra ^ k) * LD + k;   // M_A[ra][k] = S_A[ra ^ k][k]
-            const int ib = (k ^ cb) * LD + k;   // M_B[k][cb] = S_B[k ^ cb][k]
-            const float are = Are[ia], aim = Aim[ia], bre = Bre[ib], bim = Bim[ib];
-            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, cre, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-aim, bim, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bim, cim, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bre, cim, 0, 0, 0);
-        }
-    }
-    __syncthreads();  // every wave is done reading A and B
-
-    // ---- 4. C back to LDS, skewed: S_C[r ^ c][c] = C[r][c] (reusing the A planes) ----
-    {
-        const int c = c0 + i;
+        // ---- 3. complex 64 x 64 x 64 product on the matrix cores ----
+        const int i = lane & 31, h = lane >> 5;
+        const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
+        // (Ar + i Ai)(Br + i Bi) with three real products: X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi);
+        // Re = X - Y, Im = Z - X - Y
+        float16v gx, gy, gz;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            smem[(rr ^ c) * LD + c] = cre[r];
-            smem[P + (rr ^ c) * LD + c] = cim[r];
+            gx[r] = 0.f;
+            gy[r] = 0.f;
+            gz[r] = 0.f;
         }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int x = tid & 63, plane = tid >> 6;
-        const float* row = smem + plane * P + x * LD;
-        float v[64];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) v[c] = row[c];
-        wht64(v);
-        // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3
-        float* orow = p.out + item * p.out_stride;
-        const int32_t* om = p.out_map + x * 64;
-#pragma unroll
-        for (int z = 0; z < 64; ++z) {
-            const int32_t e = om[z];
-            if (e >= 0 && ((e >> 16) & 1) == plane) {
-                float val = v[z] * (1.0f / 64.0f);
-                if ((e >> 17) & 1) val = -val;
-                const int off = e & 0xffff;
-                orow[off] = p.beta ? orow[off] + val : val;
+        if (!(p.debug_skip & 4)) {
+            const float* Are = smem;
+            const float* Aim = smem + P;
+            const float* Bre = smem + 2 * P;
+            const float* Bim = smem + 3 * P;
+            const int ra = r0 + i, cb = c0 + i;
+#pragma unroll 4
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const int k = 2 * s2 + h;
+                const int ia = (ra ^ k) * LD + k;   // M_A[ra][k] = S_A[ra ^ k][k]
+                const int ib = (k ^ cb) * LD + k;   // M_B[k][cb] = S_B[k ^ cb][k]
+                const float are = Are[ia], aim = Aim[ia], bre = Bre[ib], bim = Bim[ib];
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, gz, 0, 0, 0);
             }
         }
+        __syncthreads();  // every wave is done reading A and B
+
+        // ---- 4. C back to LDS, skewed: S_C[r ^ c][c] = C[r][c] (reusing the A planes) ----
+        {
+            const int c = c0 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                smem[(rr ^ c) * LD + c] = gx[r] - gy[r];
+                smem[P + (rr ^ c) * LD + c] = gz[r] - gx[r] - gy[r];
+            }
+        }
+        __syncthreads();
+        // inverse transform in place: V[x][z] = 2^-6 sum_c (-1)^|c & z| S_C[x][c]
+        // two threads per row (adjacent lanes): thread hb folds the halves with sign (-1)^hb, a 32-point
+        // transform then gives the outputs z = j + 32 hb
+        if (!(p.debug_skip & 8)) {
+            const int hb = tid & 1;
+            float* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
+            const float sg = hb ? -1.0f / 64.0f : 1.0f / 64.0f;
+            float v[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = row[c] * (1.0f / 64.0f) + row[c + 32] * sg;
+            wht<32>(v);
+#pragma unroll
+            for (int z = 0; z < 32; ++z) row[z + 32 * hb] = v[z];   // same wave as the partner's reads: ordered
+        }
+        __syncthreads();
+        // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3; rows written in order
+        if (!(p.debug_skip & 8)) {
+            float* orow = p.out + item * p.out_stride;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t eo = entry(om, u);
+                if (eo != NONE) {
+                    const uint32_t k = (eo >> 13) & 3u;
+                    float val = smem[((k & 1u) ? P : 0) + int(eo & 0x1fffu)];
+                    if (k & 2u) val = -val;
+                    const int off = tid + 256 * u;
+                    orow[off] = p.beta ? orow[off] + val : val;
+                }
+            }
+        }
+        __syncthreads();  // the planes are free for the next item
     }
 }
 

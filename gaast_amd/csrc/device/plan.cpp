@@ -345,29 +345,31 @@ struct Lowering {
             s.n_entries = nd.n_comp_muls;
             s.use_spinor = 1;
             const int n = 12;
-            // entry: row offset | (x*65 + z) << 16 | k << 29 | (negate while staging) << 31
-            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, std::vector<uint32_t>& map, int* full) {
+            // 4096 entries indexed by row offset, two 16-bit entries per word:
+            // (x*65 + z) | k << 13 | (negate while staging) << 15, 0xffff = nothing there
+            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, bool shift_by_x, std::vector<uint32_t>& packed, int* full) {
+                std::vector<uint16_t> map(size_t(1) << n, uint16_t(0xffffu));
+                size_t count = 0;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
-                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
+                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x8000u : 0u;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
                         uint32_t px, pz, pk;
                         pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
-                        map.push_back(uint32_t(lay.offset(k) + i) | ((px * 65u + pz) << 16) | (pk << 29) | sgn);
+                        // right operand: its transformed rows are stored shifted by x, i.e. (-1)^|x&z| here
+                        const uint32_t sh = shift_by_x && (__builtin_popcount(px & pz) & 1) ? 0x8000u : 0u;
+                        map[size_t(lay.offset(k) + i)] = uint16_t((px * 65u + pz) | (pk << 13) | (sgn ^ sh));
+                        ++count;
                     }
                 }
-                *full = map.size() == (size_t(1) << n);
+                *full = count == (size_t(1) << n);
+                packed.resize(map.size() / 2);
+                std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
             };
-            build_map(ll, lmin & ll.mask, flip_l, s.u32_a, &s.left_full);
-            build_map(lrr, rmin & lrr.mask, flip_r, s.u32_b, &s.right_full);
-            s.i32_a.assign(size_t(1) << n, -1);
-            for (uint32_t m = 0; m < (1u << n); ++m) {
-                const int g = __builtin_popcount(m);
-                if (!((omin >> g) & 1ULL)) continue;
-                uint32_t px, pz, pk;
-                pauli_string(m, &px, &pz, &pk);
-                s.i32_a[px * 64u + pz] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (pk << 16));
-            }
+            int out_full = 0;
+            build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full);
+            build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full);
+            build_map(lr, omin, 0, false, s.u32_c, &out_full);
             touch(res);
             return;
         }

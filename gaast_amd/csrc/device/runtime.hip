@@ -189,21 +189,28 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 q.left_stride = a.stride;
                 q.right_stride = b.stride;
                 q.out_stride = res.stride;
-                q.left_map = static_cast<const uint32_t*>(s.d_a);
-                q.right_map = static_cast<const uint32_t*>(s.d_b);
-                q.left_count = int(s.u32_a.size());
-                q.right_count = int(s.u32_b.size());
+                q.left_map = static_cast<const uint16_t*>(s.d_a);
+                q.right_map = static_cast<const uint16_t*>(s.d_b);
                 q.left_full = s.left_full;
                 q.right_full = s.right_full;
-                q.out_map = static_cast<const int32_t*>(s.d_i32);
+                q.out_map = static_cast<const uint16_t*>(s.d_c);
+                q.left_len = int(la.row_len);
+                q.right_len = int(lb.row_len);
                 q.canon_left = s.canon_a;
                 q.canon_right = s.canon_b;
                 q.beta = s.beta;
                 q.batch = batch;
+                static const int sdbg = std::getenv("GAAST_DEBUG_DENSE_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_DENSE_SKIP")) : 0;
+                q.debug_skip = sdbg;
                 const size_t lds = size_t(4) * 64 * 65 * sizeof(float);
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_spinor12),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-                hipLaunchKernelGGL(k_gp_spinor12, dim3(unsigned(batch)), dim3(256), lds, g_stream, q);
+                int per_cu = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_gp_spinor12), 256, lds));
+                if (per_cu < 1) per_cu = 1;
+                int64_t blocks = int64_t(g_num_cu) * per_cu;
+                if (blocks > batch) blocks = batch;
+                hipLaunchKernelGGL(k_gp_spinor12, dim3(unsigned(blocks)), dim3(256), lds, g_stream, q);
                 break;
             }
             return set_err(GAAST_ERR_INVALID_PROGRAM, "matrix-representation product is f32 only");
