@@ -885,30 +885,41 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // bijection onto 6-bit pairs.  (X^x Z^z)[c^x][c] = (-1)^|c & z|, so for the multivector A
 //     M_A[c ^ x][c] = sum_z (-1)^|c & z| * i^k(x,z) A_{S(x,z)}       -- a Walsh-Hadamard transform
 // over z of row x of the re-indexed components; the product is C = M_A M_B (complex 64^3
-// GEMM = 4 real ones = 512 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
+// GEMM = 3 real ones = 384 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
 // transform of the skewed diagonals of C gives the components back.
 //
-// Workgroup = one item, 256 threads.  LDS: four 64 x 65 f32 planes (A re/im, B re/im; the +1
-// column makes both the row-wise and the XOR-skewed column-wise accesses conflict-free).
-//   1. scatter the graded rows into W[x][z] (table: row offset | plane position | k | negate)
-//   2. 256 threads = 256 row transforms (2 operands x re/im x 64 rows), 64 values in registers;
-//      A rows are written back in place (S_A[x][c] = M_A[c^x][c]), B rows XOR-permuted
-//      (S_B[x][r] = M_B[r][r^x]) so that both MFMA operand gathers hit 32 distinct banks
-//   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair 4 ds_read_b32 and 4 MFMAs
-//   4. C tiles go back to LDS skewed, 128 row transforms, and each transformed value is the
-//      component of one blade (real part for even k, imaginary for odd k).
+// Workgroup = 256 threads, persistent over items.  LDS: four 64 x 65 f32 planes (A re/im, B re/im;
+// the +1 column makes the row-wise and the XOR-skewed column-wise accesses conflict-free, and
+// 4160 words = 65 x 256 B lets one ds_read2st64_b32 fetch re and im together).
+//   1. scatter the graded rows into W[x][z] from registers (16-bit table entries, branch-free)
+//   2. 256 threads = 256 row transforms (2 operands x re/im x 64 rows), 64 values in registers,
+//      written back in place: S_A[x][c] = M_A[c^x][c]; S_B[x][r] = M_B[r][r^x] -- the shift by x
+//      of B's transform is a sign (-1)^|x&z| on its input, folded into the right operand's table --
+//      so both MFMA operand gathers hit 32 distinct banks
+//   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair two LDS reads and THREE MFMAs
+//      (X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y), operands of the next
+//      step read while the current MFMAs run
+//   4. C tiles go back to LDS skewed; two threads per row fold and transform 32 points each;
+//      every transformed value is the component of one blade (real part for even k, imaginary
+//      for odd k), gathered in row order so that the stores to HBM are coalesced.
+// The operands of the next item are loaded into registers during steps 2-4.
+// Measured (profiles/r01_r12s_*): 32 M products/s at B = 65536, 8.7x the contraction kernel.
 // ------------------------------------------------------------------------------------------
 struct SpinorArgs {
     const float* left;
     const float* right;
     float* out;
     int64_t left_stride, right_stride, out_stride;
-    // 4096 entries each, indexed by ROW OFFSET: x*65+z [12:0] | k [14:13] | negate [15];
-    // 0xffff = offset beyond the row / grade not wanted
+    // 4096 16-bit entries each, indexed by ROW OFFSET (two per word).
+    //  operands: bit 0 = negate (folded unary signs, i^2, the right operand's shift), bit 1 = plane
+    //            (0 real, 1 imaginary: parity of k), bits [14:2] = x*65+z, i.e. entry & 0x7ffc is the byte
+    //            offset inside a plane; offsets that hold nothing point at a padding word (x*65+z = 64)
+    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = plane*4160 + x*65+z
     const uint16_t* left_map;
     const uint16_t* right_map;
     const uint16_t* out_map;
     int left_len, right_len;
+    int out_full;
     int left_full, right_full;
     int canon_left, canon_right;
     int beta;
@@ -938,7 +949,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int D = 64, LD = 65, P = D * LD;  // plane = 64 rows of 65
-    constexpr uint32_t NONE = 0xffffu;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
 
@@ -950,30 +960,29 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
         rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
         om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
     }
-    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (m[u >> 1] >> ((u & 1) * 16)) & 0xffffu; };
+    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
     float va[16], vb[16];
+    const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
     auto fetch = [&](int64_t item) {
-        const float* lrow = p.left + item * p.left_stride;
-        const float* rrow = p.right + item * p.right_stride;
+        const float* lrow = p.left + item * p.left_stride + tid;
+        const float* rrow = p.right + item * p.right_stride + tid;
+        if (rows_full) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = tid + 256 * u;
-            va[u] = e < p.left_len ? lrow[e] : 0.f;
-            vb[u] = e < p.right_len ? rrow[e] : 0.f;
+            for (int u = 0; u < 16; ++u) {
+                va[u] = lrow[256 * u];
+                vb[u] = rrow[256 * u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + 256 * u;
+                va[u] = e < p.left_len ? lrow[256 * u] : 0.f;
+                vb[u] = e < p.right_len ? rrow[256 * u] : 0.f;
+            }
         }
     };
     int64_t item = blockIdx.x;
     if (item < p.batch) fetch(item);
-    // Two workgroups share a CU.  Started together they run in lockstep (both in the GEMM, then both
-    // in the transforms) and the matrix cores idle two thirds of the time; the one whose LDS block
-    // does not start at 0 waits about half an item so that its GEMM overlaps the other's transforms.
-    if (!(p.debug_skip & 32)) {
-        const uint32_t lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);  // HW_REG_LDS_ALLOC, LDS_BASE in the low bits
-        if ((lds_alloc & 0xfffu) != 0) {
-            const int naps = (p.debug_skip >> 8) ? (p.debug_skip >> 8) : 3;
-            for (int d = 0; d < naps; ++d) __builtin_amdgcn_s_sleep(127);
-        }
-    }
 
     for (; item < p.batch; item += gridDim.x) {
         // keep the packed tables packed: without this the decoded fields of all 48 entries are hoisted
@@ -986,27 +995,19 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
             __syncthreads();
         }
         if (!(p.debug_skip & 1)) {
+            // branch-free: one write of (re, im) = (a, 0) or (0, a) per component
+            auto put = [&](float* planes, uint32_t e, float a, int canon) {
+                if (canon) a = 0.f + a;
+                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
+                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
+                const bool im = (e & 2u) != 0;
+                q[0] = im ? 0.f : a;
+                q[P] = im ? a : 0.f;
+            };
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const uint32_t el = entry(lm, u), er = entry(rm, u);
-                if (el != NONE) {
-                    float a = va[u];
-                    if (p.canon_left) a = 0.f + a;
-                    const uint32_t k = (el >> 13) & 3u;
-                    if (((el >> 15) ^ (k >> 1)) & 1u) a = -a;   // folded unary sign, and i^2 = -1
-                    const int pos = int(el & 0x1fffu);
-                    smem[pos] = (k & 1u) ? 0.f : a;
-                    smem[P + pos] = (k & 1u) ? a : 0.f;
-                }
-                if (er != NONE) {
-                    float b = vb[u];
-                    if (p.canon_right) b = 0.f + b;
-                    const uint32_t k = (er >> 13) & 3u;
-                    if (((er >> 15) ^ (k >> 1)) & 1u) b = -b;
-                    const int pos = int(er & 0x1fffu);
-                    smem[2 * P + pos] = (k & 1u) ? 0.f : b;
-                    smem[3 * P + pos] = (k & 1u) ? b : 0.f;
-                }
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + 2 * P, entry(rm, u), vb[u], p.canon_right);
             }
         }
         __syncthreads();
@@ -1045,16 +1046,39 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
             const float* Aim = smem + P;
             const float* Bre = smem + 2 * P;
             const float* Bim = smem + 3 * P;
-            const int ra = r0 + i, cb = c0 + i;
-#pragma unroll 4
+            (void)Are; (void)Aim; (void)Bre; (void)Bim;
+            const uint32_t ra = uint32_t(r0 + i), cb = uint32_t(c0 + i);
+            const uint32_t lds0 = uint32_t(uintptr_t(smem));
+            const uint32_t row_bytes = LD * 4;
+            // M_A[ra][k] = S_A[ra ^ k][k], M_B[k][cb] = S_B[k ^ cb][k].  Hand-scheduled: the operands
+            // of step s2+1 are read (re and im planes with one ds_read2st64) while the three MFMAs of
+            // step s2 run; byte address = (row * 65 + k) * 4 with a 24-bit multiply-add.
+            float2v av[2], bv[2];
+            uint32_t k4 = lds0 + 4u * uint32_t(h), kk = uint32_t(h);
+            auto issue = [&](float2v& a, float2v& b) {
+                uint32_t aa, ab;
+                // the running k (and 4k + base) are advanced inside the asm so that the 32 unrolled
+                // values are not precomputed outside the item loop (and spilled)
+                asm volatile("v_xor_b32 %0, %4, %2\n\tv_xor_b32 %1, %5, %2\n\t"
+                             "v_mad_u32_u24 %0, %0, %6, %3\n\tv_mad_u32_u24 %1, %1, %6, %3\n\t"
+                             "v_add_u32 %2, 2, %2\n\tv_add_u32 %3, 8, %3"
+                             : "=&v"(aa), "=&v"(ab), "+v"(kk), "+v"(k4) : "v"(ra), "v"(cb), "s"(row_bytes));
+                asm volatile("ds_read2st64_b32 %0, %1 offset1:65" : "=v"(a) : "v"(aa));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:130 offset1:195" : "=v"(b) : "v"(ab));
+            };
+            issue(av[0], bv[0]);
+#pragma unroll
             for (int s2 = 0; s2 < 32; ++s2) {
-                const int k = 2 * s2 + h;
-                const int ia = (ra ^ k) * LD + k;   // M_A[ra][k] = S_A[ra ^ k][k]
-                const int ib = (k ^ cb) * LD + k;   // M_B[k][cb] = S_B[k ^ cb][k]
-                const float are = Are[ia], aim = Aim[ia], bre = Bre[ib], bim = Bim[ib];
-                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, gz, 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float2v& a = av[s2 & 1];
+                float2v& b = bv[s2 & 1];
+                asm volatile("" : "+v"(a), "+v"(b));   // the reads above have landed: values are live from here
+                if (s2 < 31) issue(av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, gz, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();  // every wave is done reading A and B
@@ -1087,16 +1111,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
         __syncthreads();
         // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3; rows written in order
         if (!(p.debug_skip & 8)) {
-            float* orow = p.out + item * p.out_stride;
+            float* orow = p.out + item * p.out_stride + tid;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t eo = entry(om, u);
-                if (eo != NONE) {
-                    const uint32_t k = (eo >> 13) & 3u;
-                    float val = smem[((k & 1u) ? P : 0) + int(eo & 0x1fffu)];
-                    if (k & 2u) val = -val;
-                    const int off = tid + 256 * u;
-                    orow[off] = p.beta ? orow[off] + val : val;
+                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
+                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[256 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
                 }
             }
         }

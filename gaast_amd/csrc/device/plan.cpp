@@ -345,20 +345,22 @@ struct Lowering {
             s.n_entries = nd.n_comp_muls;
             s.use_spinor = 1;
             const int n = 12;
-            // 4096 entries indexed by row offset, two 16-bit entries per word:
-            // (x*65 + z) | k << 13 | (negate while staging) << 15, 0xffff = nothing there
-            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, bool shift_by_x, std::vector<uint32_t>& packed, int* full) {
-                std::vector<uint16_t> map(size_t(1) << n, uint16_t(0xffffu));
+            // 4096 16-bit entries indexed by row offset, two per word (formats: SpinorArgs, kernels.hip.hpp)
+            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
+                // role 0 = left, 1 = right (transformed rows stored shifted by x: (-1)^|x&z| here), 2 = result
+                const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(64u << 2);
+                std::vector<uint16_t> map(size_t(1) << n, nothing);
                 size_t count = 0;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
-                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x8000u : 0u;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
                         uint32_t px, pz, pk;
                         pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
-                        // right operand: its transformed rows are stored shifted by x, i.e. (-1)^|x&z| here
-                        const uint32_t sh = shift_by_x && (__builtin_popcount(px & pz) & 1) ? 0x8000u : 0u;
-                        map[size_t(lay.offset(k) + i)] = uint16_t((px * 65u + pz) | (pk << 13) | (sgn ^ sh));
+                        uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
+                        if (role == 1) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
+                        const uint32_t pos = px * 65u + pz;
+                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * 4160u + pos) << 2 | neg)
+                                                                   : uint16_t(pos << 2 | (pk & 1u) << 1 | neg);
                         ++count;
                     }
                 }
@@ -366,10 +368,9 @@ struct Lowering {
                 packed.resize(map.size() / 2);
                 std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
             };
-            int out_full = 0;
-            build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full);
-            build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full);
-            build_map(lr, omin, 0, false, s.u32_c, &out_full);
+            build_map(ll, lmin & ll.mask, flip_l, 0, s.u32_a, &s.left_full);
+            build_map(lrr, rmin & lrr.mask, flip_r, 1, s.u32_b, &s.right_full);
+            build_map(lr, omin, 0, 2, s.u32_c, &s.out_full);
             touch(res);
             return;
         }

@@ -48,7 +48,7 @@ struct Step {
     int sunary_op = 0, sunary_off = 0;
     int canon_a = 0, canon_b = 0;
     int beta = 1;
-    int left_full = 0, right_full = 0;
+    int left_full = 0, right_full = 0, out_full = 0;
     int left_contig = 0, right_contig = 0;
     uint32_t neg_hi = 0, zero_hi = 0;
     int degenerate = 0;

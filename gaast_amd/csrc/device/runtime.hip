@@ -194,6 +194,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 q.left_full = s.left_full;
                 q.right_full = s.right_full;
                 q.out_map = static_cast<const uint16_t*>(s.d_c);
+                q.out_full = s.out_full;
                 q.left_len = int(la.row_len);
                 q.right_len = int(lb.row_len);
                 q.canon_left = s.canon_a;
