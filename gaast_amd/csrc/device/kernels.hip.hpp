@@ -899,7 +899,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 //   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair two LDS reads and THREE MFMAs
 //      (X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y), operands of the next
 //      step read while the current MFMAs run
-//   4. C tiles go back to LDS skewed; two threads per row fold and transform 32 points each;
+//   4. C tiles go back to LDS skewed (by r, conflict-free); two threads per row fold and transform 32 points each;
 //      every transformed value is the component of one blade (real part for even k, imaginary
 //      for odd k), gathered in row order so that the stores to HBM are coalesced.
 // The operands of the next item are loaded into registers during steps 2-4.
@@ -1083,14 +1083,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
         }
         __syncthreads();  // every wave is done reading A and B
 
-        // ---- 4. C back to LDS, skewed: S_C[r ^ c][c] = C[r][c] (reusing the A planes) ----
+        // ---- 4. C back to LDS, skewed: S_C[r ^ c][r] = C[r][c] (reusing the A planes).  Indexing the
+        // diagonal x = r ^ c by r (not c) keeps the 32 lanes of a store on 32 banks; the transform of a
+        // row shifted by x is the wanted one times (-1)^|x&z|, a sign the result table carries. ----
         {
             const int c = c0 + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                smem[(rr ^ c) * LD + c] = gx[r] - gy[r];
-                smem[P + (rr ^ c) * LD + c] = gz[r] - gx[r] - gy[r];
+                smem[(rr ^ c) * LD + rr] = gx[r] - gy[r];
+                smem[P + (rr ^ c) * LD + rr] = gz[r] - gx[r] - gy[r];
             }
         }
         __syncthreads();

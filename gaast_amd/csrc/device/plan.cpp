@@ -347,7 +347,8 @@ struct Lowering {
             const int n = 12;
             // 4096 16-bit entries indexed by row offset, two per word (formats: SpinorArgs, kernels.hip.hpp)
             auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
-                // role 0 = left, 1 = right (transformed rows stored shifted by x: (-1)^|x&z| here), 2 = result
+                // role 0 = left, 1 = right, 2 = result; the transformed rows of the right operand and of the
+                // result are stored shifted by x, which is the sign (-1)^|x&z| here
                 const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(64u << 2);
                 std::vector<uint16_t> map(size_t(1) << n, nothing);
                 size_t count = 0;
@@ -357,7 +358,7 @@ struct Lowering {
                         uint32_t px, pz, pk;
                         pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
                         uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
-                        if (role == 1) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
+                        if (role != 0) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
                         const uint32_t pos = px * 65u + pz;
                         map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * 4160u + pos) << 2 | neg)
                                                                    : uint16_t(pos << 2 | (pk & 1u) << 1 | neg);
