@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r8|cl41]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r8|r8s|cl41]
 
 A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
 multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
@@ -55,6 +55,13 @@ def workload_spec(name):
                     build=lambda a, b: a * b, entries=4 ** n, default_batch=65536, flags=ga.FLAG_SPINOR_GEMM,
                     flops_item=2 * 3 * 64 ** 3 + 2 * 384 * (256 + 64),
                     label="R^12 full MV x MV geometric product, f32, opt-in 64x64 complex matrix representation")
+    if name == "r8s":
+        n = 8
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F32, dtname="f32", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=1 << 20, flags=ga.FLAG_SPINOR_GEMM,
+                    flops_item=2 * 3 * 16 ** 3 + 2 * 64 * (64 + 16),
+                    label="R^8 full MV x MV geometric product, f32, opt-in 16x16 complex matrix representation")
     if name == "r8":
         n = 8
         full = list(range(n + 1))

@@ -1130,4 +1130,145 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
     }
 }
 
+// Same algorithm for the smaller even dimensions: n = 8 (16 x 16 matrices, v_mfma_f32_16x16x4_f32)
+// and n = 10 (32 x 32, v_mfma_f32_32x32x2_f32); odd n runs as the subalgebra of n + 1.  One WAVE per
+// item (64-thread workgroups, persistent), so the phases need no cross-wave barrier, and the four
+// planes of an item are 5 KB / 17 KB of LDS.  Plane stride = a multiple of 64 words (re/im pairs by
+// ds_read2st64).  Table formats as in SpinorArgs with 65 -> D + 1 and 4160 -> the plane stride.
+template <int M>
+__global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int D = 1 << M, LD = D + 1, P = D * LD;
+    constexpr int PS = (P + 63) / 64 * 64;
+    constexpr int NE = D * D, EPL = NE / 64, RPL = 4 * D / 64;
+    using acc_t = typename std::conditional<M == 4, float4v, float16v>::type;
+    constexpr int NACC = M == 4 ? 4 : 16;
+    const int lane = threadIdx.x;
+
+    uint32_t lm[EPL / 2], rm[EPL / 2], om[EPL / 2];
+#pragma unroll
+    for (int w = 0; w < EPL / 2; ++w) {
+        lm[w] = uint32_t(p.left_map[lane + 128 * w]) | (uint32_t(p.left_map[lane + 128 * w + 64]) << 16);
+        rm[w] = uint32_t(p.right_map[lane + 128 * w]) | (uint32_t(p.right_map[lane + 128 * w + 64]) << 16);
+        om[w] = uint32_t(p.out_map[lane + 128 * w]) | (uint32_t(p.out_map[lane + 128 * w + 64]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[EPL / 2], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    float va[EPL], vb[EPL];
+    auto fetch = [&](int64_t item) {
+        const float* lrow = p.left + item * p.left_stride + lane;
+        const float* rrow = p.right + item * p.right_stride + lane;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = lane + 64 * u;
+            va[u] = e < p.left_len ? lrow[64 * u] : 0.f;
+            vb[u] = e < p.right_len ? rrow[64 * u] : 0.f;
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+
+    for (; item < p.batch; item += gridDim.x) {
+#pragma unroll
+        for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        if (!p.left_full || !p.right_full) {
+            for (int i = lane; i < 4 * PS; i += 64) smem[i] = 0.f;
+            __syncthreads();
+        }
+        {
+            auto put = [&](float* planes, uint32_t e, float a, int canon) {
+                if (canon) a = 0.f + a;
+                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
+                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
+                const bool im = (e & 2u) != 0;
+                q[0] = im ? 0.f : a;
+                q[PS] = im ? a : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + 2 * PS, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+
+        // row transforms: (operand, plane, x) = 4 D rows over 64 lanes
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int ridx = lane + 64 * j;
+            float* row = smem + (ridx >> M) * PS + (ridx & (D - 1)) * LD;
+            float v[D];
+#pragma unroll
+            for (int z = 0; z < D; ++z) v[z] = row[z];
+            wht<D>(v);
+#pragma unroll
+            for (int c = 0; c < D; ++c) row[c] = v[c];
+        }
+        __syncthreads();
+
+        // complex D x D x D product, three real ones (see k_gp_spinor12)
+        acc_t gx, gy, gz;
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            gx[r] = 0.f;
+            gy[r] = 0.f;
+            gz[r] = 0.f;
+        }
+        const int i = lane & (D - 1);
+        const int kq = lane >> M;                 // M = 4: 0..3 (k = 4 s + kq);  M = 5: 0..1 (k = 2 s + kq)
+        constexpr int KSTEP = 64 / D;             // k values per MFMA
+#pragma unroll
+        for (int s2 = 0; s2 < D / KSTEP; ++s2) {
+            const int k = KSTEP * s2 + kq;
+            const int idx = (i ^ k) * LD + k;     // M_A[i][k] = S_A[i^k][k], M_B[k][i] = S_B[k^i][k]
+            const float are = smem[idx], aim = smem[PS + idx], bre = smem[2 * PS + idx], bim = smem[3 * PS + idx];
+            if constexpr (M == 4) {
+                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(are, bre, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_16x16x4f32(aim, bim, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_16x16x4f32(are + aim, bre + bim, gz, 0, 0, 0);
+            } else {
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, gz, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // C back, diagonals indexed by row: S_C[r ^ c][r] = C[r][c]
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
+            smem[(rr ^ i) * LD + rr] = gx[r] - gy[r];
+            smem[PS + (rr ^ i) * LD + rr] = gz[r] - gx[r] - gy[r];
+        }
+        __syncthreads();
+        // inverse transform: (plane, x, half) = 4 D half-rows over 64 lanes
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int hidx = lane + 64 * j;
+            const int hb = hidx & 1;
+            float* row = smem + (hidx >> (M + 1)) * PS + ((hidx >> 1) & (D - 1)) * LD;
+            const float sc = 1.0f / float(D), sg = hb ? -sc : sc;
+            float v[D / 2];
+#pragma unroll
+            for (int c = 0; c < D / 2; ++c) v[c] = row[c] * sc + row[c + D / 2] * sg;
+            wht<D / 2>(v);
+#pragma unroll
+            for (int z = 0; z < D / 2; ++z) row[z + (D / 2) * hb] = v[z];
+        }
+        __syncthreads();
+        {
+            float* orow = p.out + item * p.out_stride + lane;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const uint32_t eo = entry(om, u);
+                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
+                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (!(eo & 2u)) orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace gaast

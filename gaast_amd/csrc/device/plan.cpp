@@ -277,16 +277,18 @@ struct Lowering {
         return double(nd.n_comp_muls) * 8.0 >= full;  // the tiled kernel always does 4^n multiply-adds
     }
 
-    // opt-in matrix-representation kernel (k_gp_spinor12): f32, n = 12, every vector squares to +-1
+    // opt-in matrix-representation kernels: f32, n = 7..12 (odd n as the subalgebra of n + 1), every
+    // vector squaring to +-1
     bool spinor_eligible(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r) const {
         if (!(plan.flags & GAAST_FLAG_SPINOR_GEMM)) return false;
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
-        if (plan.dtype != GAAST_F32 || d.vec_space_dim != 12) return false;
-        if (layout(res).dim != 12 || layout(l).dim != 12 || layout(r).dim != 12) return false;
-        for (int i = 0; i < 12; ++i)
+        const int n = d.vec_space_dim;
+        if (plan.dtype != GAAST_F32 || n < 7 || n > 12) return false;
+        if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return false;
+        for (int i = 0; i < n; ++i)
             if (d.metric_diag[i] != 1.0 && d.metric_diag[i] != -1.0) return false;
         if (!is_geometric_list(nd)) return false;
-        return double(nd.n_comp_muls) * 8.0 >= double(uint64_t(1) << 24);
+        return double(nd.n_comp_muls) * 8.0 >= double(uint64_t(1) << (2 * n));
     }
 
     // blade -> Pauli string i^k X^x Z^z under the Jordan-Wigner generators (kernels.hip.hpp)
@@ -336,21 +338,23 @@ struct Lowering {
             }
             const bool beta0 = is_fresh && (lr.mask & ~omin) == 0;
             if (beta0) removed[size_t(fr->second)] = 1;
-            Step& s = emit(Step::PRODUCT_DENSE, res, "product_spinor_gemm[gp n=12]");
+            const int n = d.vec_space_dim;
+            const int m = (n + 1) / 2;                 // 2^m x 2^m complex matrices
+            const uint32_t D = 1u << m, LD = D + 1u, PS = (D * LD + 63u) / 64u * 64u;
+            Step& s = emit(Step::PRODUCT_DENSE, res, "product_spinor_gemm[gp n=" + std::to_string(n) + "]");
             s.a = l;
             s.b = r;
             s.canon_a = canon_l;
             s.canon_b = canon_r;
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
-            s.use_spinor = 1;
-            const int n = 12;
-            // 4096 16-bit entries indexed by row offset, two per word (formats: SpinorArgs, kernels.hip.hpp)
+            s.use_spinor = m;
+            // D*D 16-bit entries indexed by row offset, two per word (formats: SpinorArgs, kernels.hip.hpp)
             auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
                 // role 0 = left, 1 = right, 2 = result; the transformed rows of the right operand and of the
                 // result are stored shifted by x, which is the sign (-1)^|x&z| here
-                const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(64u << 2);
-                std::vector<uint16_t> map(size_t(1) << n, nothing);
+                const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(D << 2);   // padding word of row 0
+                std::vector<uint16_t> map(size_t(D) * D, nothing);
                 size_t count = 0;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
@@ -359,13 +363,13 @@ struct Lowering {
                         pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
                         uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
                         if (role != 0) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
-                        const uint32_t pos = px * 65u + pz;
-                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * 4160u + pos) << 2 | neg)
+                        const uint32_t pos = px * LD + pz;
+                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * PS + pos) << 2 | neg)
                                                                    : uint16_t(pos << 2 | (pk & 1u) << 1 | neg);
                         ++count;
                     }
                 }
-                *full = count == (size_t(1) << n);
+                *full = count == size_t(D) * D;
                 packed.resize(map.size() / 2);
                 std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
             };

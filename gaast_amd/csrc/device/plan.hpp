@@ -53,7 +53,7 @@ struct Step {
     uint32_t neg_hi = 0, zero_hi = 0;
     int degenerate = 0;
     int use_mfma = 0;
-    int use_spinor = 0;  // opt-in matrix-representation kernel (GAAST_FLAG_SPINOR_GEMM)
+    int use_spinor = 0;  // opt-in matrix-representation kernel (GAAST_FLAG_SPINOR_GEMM): log2 of the matrix size, or 0
     uint64_t n_entries = 0;  // comp-mul count this step stands for
     // FUSED: the whole plan as one micro-op stream over per-item LDS slabs (u32_a = the stream)
     struct FusedInput {

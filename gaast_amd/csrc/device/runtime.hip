@@ -203,15 +203,21 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 q.batch = batch;
                 static const int sdbg = std::getenv("GAAST_DEBUG_DENSE_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_DENSE_SKIP")) : 0;
                 q.debug_skip = sdbg;
-                const size_t lds = size_t(4) * 64 * 65 * sizeof(float);
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_spinor12),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+                using KernS = void (*)(SpinorArgs);
+                const int m = s.use_spinor;
+                const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
+                const size_t lds = 4 * plane * sizeof(float);
+                KernS kern = m == 6 ? &k_gp_spinor12 : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
+                const int threads = m == 6 ? 256 : 64;
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
                 int per_cu = 0;
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_gp_spinor12), 256, lds));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
                 if (per_cu < 1) per_cu = 1;
                 int64_t blocks = int64_t(g_num_cu) * per_cu;
                 if (blocks > batch) blocks = batch;
-                hipLaunchKernelGGL(k_gp_spinor12, dim3(unsigned(blocks)), dim3(256), lds, g_stream, q);
+                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, q);
                 break;
             }
             return set_err(GAAST_ERR_INVALID_PROGRAM, "matrix-representation product is f32 only");

@@ -273,6 +273,47 @@ def test_spinor_gemm_basis_blades_exact(metric):
         assert np.array_equal(got[i], want), (i, a, b)
 
 
+@pytest.mark.parametrize("n,neg", [(7, ()), (8, ()), (8, (0, 3, 6)), (9, (1, 8)), (10, ()), (10, (2, 3, 9)), (11, (0, 10))])
+def test_spinor_gemm_smaller_dimensions(n, neg):
+    """n = 8 and 10 on the wave-per-item kernels, odd n as the subalgebra of n + 1."""
+    metric = [-1.0 if i in neg else 1.0 for i in range(n)]
+    batch = 67
+    rng = np.random.default_rng(30 + n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    for i in range(0, batch, 11):
+        A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
+        want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
+        bound = 64 * 2.0 ** -23 * np.linalg.norm(rows[0][i].astype(np.float64)) * np.linalg.norm(rows[1][i].astype(np.float64))
+        err = np.abs(got[i].astype(np.float64) - want).max()
+        assert err <= bound, (i, err, bound)
+
+
+@pytest.mark.parametrize("n", [8, 9, 10])
+def test_spinor_gemm_smaller_dimensions_basis_blades_exact(n):
+    metric = [-1.0 if i % 3 == 1 else 1.0 for i in range(n)]
+    N = 1 << n
+    rng = np.random.default_rng(40 + n)
+    batch = 300
+    a_idx, b_idx = rng.integers(0, N, batch), rng.integers(0, N, batch)
+    ra, rb = np.zeros((batch, N), np.float32), np.zeros((batch, N), np.float32)
+    ra[np.arange(batch), a_idx] = 1.0
+    rb[np.arange(batch), b_idx] = 1.0
+    got, _, spec = hip_eval_batch(_gp(n), metric, {0: ra, 1: rb}, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches())
+    from helpers import blades_in_row_order
+    blades = blades_in_row_order(n, full_grades(n))
+    pos_of = np.zeros(N, dtype=np.int64)
+    pos_of[blades] = np.arange(N)
+    alg = ga.MetricAlgebra(metric)
+    for i in range(batch):
+        res, coeff = alg.ortho_basis_blades_gp(int(blades[a_idx[i]]), int(blades[b_idx[i]]))
+        want = np.zeros(N, np.float32)
+        want[pos_of[res]] = coeff
+        assert np.array_equal(got[i], want), (i,)
+
+
 def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand():
     """rotor-like even operand (shared by all items), reversed on the fly, odd result only."""
     n, batch = 12, 3
