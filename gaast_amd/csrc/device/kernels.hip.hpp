@@ -1155,14 +1155,23 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
     }
     auto entry = [](const uint32_t (&m)[EPL / 2], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
     float va[EPL], vb[EPL];
+    const bool rows_full = p.left_len == NE && p.right_len == NE;
     auto fetch = [&](int64_t item) {
         const float* lrow = p.left + item * p.left_stride + lane;
         const float* rrow = p.right + item * p.right_stride + lane;
+        if (rows_full) {
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) {
-            const int e = lane + 64 * u;
-            va[u] = e < p.left_len ? lrow[64 * u] : 0.f;
-            vb[u] = e < p.right_len ? rrow[64 * u] : 0.f;
+            for (int u = 0; u < EPL; ++u) {
+                va[u] = lrow[64 * u];
+                vb[u] = rrow[64 * u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int e = lane + 64 * u;
+                va[u] = e < p.left_len ? lrow[64 * u] : 0.f;
+                vb[u] = e < p.right_len ? rrow[64 * u] : 0.f;
+            }
         }
     };
     int64_t item = blockIdx.x;
@@ -1264,7 +1273,11 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
                 const uint32_t eo = entry(om, u);
                 float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
                 val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
-                if (!(eo & 2u)) orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+                if (p.out_full && !p.beta) {
+                    orow[64 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+                }
             }
         }
         __syncthreads();
