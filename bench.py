@@ -113,9 +113,15 @@ def cpu_baseline(wl, budget_s=12.0):
     # copy of the inputs (the reference is single-threaded and !Send, so this is its embarrassingly
     # parallel ceiling: independent evaluations in independent processes)
     cores = len(os.sched_getaffinity(0))
+    try:  # a container's CPU share (cgroup v2) can be far below the affinity mask
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     all_cores = None
     if cores > 1:
-        per_worker = max(2, items // 2)
+        per_worker = max(2, int(0.5 * budget_s / dt))      # about half the single-core leg's wall time
         pipes, pids = [], []
         t0 = time.time()
         for _ in range(cores):

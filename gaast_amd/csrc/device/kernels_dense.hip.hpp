@@ -1,0 +1,490 @@
+// kernels_dense.hip.hpp -- dense geometric product in blade-bitmask space: vector-FMA and matrix-core kernels
+// Included through kernels.hip.hpp.
+#pragma once
+#include "kernels_common.hip.hpp"
+
+namespace gaast {
+
+// ------------------------------------------------------------------------------------------
+// Product arm, dense geometric product, tiled in blade-bitmask space.
+//
+// In bitmask space e_a e_b = s(a,b) m(a&b) e_{a^b}  (algebra.rs:73-83), a twisted
+// XOR-convolution.  Split a blade into hi = a >> 4 and lo = a & 15:
+//     s(a,b) = s_hi(a_hi,b_hi) * s_lo(a_lo,b_lo) * (-1)^(|a_hi| |b_lo|)
+// so an aligned 16-block of A times an aligned 16-block of B lands in exactly one 16-block
+// of C, with a compile-time sign pattern (two variants, by the parity of |a_hi|) and one
+// run-time sign per (a_hi, b_hi).  The lo four basis vectors must square to +1; the
+// metric of the others (+1/-1/0) is folded into the per-block sign / zero factor:
+//     (-1)^|a_hi & b_hi & NEG|  and  [a_hi & b_hi & ZERO == 0].
+//
+// Mapping: lane <-> c_hi (one 16-component block of the result in 16 accumulators),
+// 2^(n-4) lanes per item.  Both operands of the item sit in LDS in bitmask order (scattered
+// there through the index table while loading the graded rows coalesced).  Per step a_hi
+// every lane reads the A block a_hi (a broadcast) and the B block a_hi ^ c_hi (a lane
+// permutation of the blocks: conflict-free with the quad swizzle below), applies the
+// block sign to B and issues 256 FMAs.  With b = a ^ c the block sign is
+//     (-1)^( u(a_hi) + parity(c_hi & M(a_hi)) ),  M = sp(a_hi) ^ (a_hi & NEG),
+// sp = exclusive suffix parity, u = parity(a_hi & sp) ^ parity(a_hi & NEG): M and u are
+// wave-uniform (scalar ALU), the lane pays and + popcount + shift.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct DenseArgs {
+    const T* left;
+    const T* right;
+    T* out;
+    int64_t left_stride, right_stride, out_stride;
+    const uint32_t* left_map;   // per loaded component: row offset | LDS image position << 16 | negate << 31
+    const uint32_t* right_map;
+    int left_count, right_count;
+    int left_full, right_full;  // 1: every blade is loaded, no zero fill needed
+    int left_contig, right_contig;  // 1: row offsets are 0,1,2,... and rows are 16-byte aligned: vector loads
+    const int32_t* out_map;     // per bitmask: offset in the out row, or -1
+    int canon_left, canon_right;
+    int n;                      // vector-space dimension, 4 <= n
+    uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
+    int beta;
+    int64_t batch;
+};
+
+// physical position of blade bitmask m inside an operand's LDS image: blocks of 16, the four
+// 16-byte quads of block x rotated by (x >> 2) & 3 so that 16 lanes reading the same logical
+// quad of 16 different blocks touch 16 different bank quads.
+__device__ __forceinline__ int dense_lds_pos(int m) {
+    const int x = m >> 4, lo = m & 15;
+    return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
+}
+
+
+// Scatter the operand rows of `nitems` items into their LDS images.  A map word is
+//   row offset [15:0] | position in the LDS image [30:16] | negate [31]
+// (the position is computed on the host for the kernel that consumes the image).  Loads of a
+// trip are all issued before the first use.  When the offsets are simply 0, 1, 2, ... (an
+// operand holding every blade) four consecutive components move per 16-byte load.
+template <typename T, int THREADS>
+__device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_t stride, const uint32_t* __restrict__ map,
+                                               int count, int contig4, int canon, T* __restrict__ images,
+                                               int image_stride, int nitems, int tid) {
+    constexpr int U = 4;
+    if (contig4) {
+        const int total4 = (nitems * count) >> 2;  // count % 4 == 0
+        const int count4 = count >> 2;
+        for (int e0 = tid; e0 < total4; e0 += THREADS * U) {
+            uint4 m[U];
+            T v[U][4];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + k * THREADS;
+                if (e < total4) {
+                    const int it = e / count4, j4 = e - it * count4;
+                    m[k] = reinterpret_cast<const uint4*>(map)[j4];
+                    const T* rp = src + int64_t(it) * stride + (j4 << 2);
+                    if (sizeof(T) == 4) {
+                        const float4 f = *reinterpret_cast<const float4*>(rp);
+                        v[k][0] = T(f.x); v[k][1] = T(f.y); v[k][2] = T(f.z); v[k][3] = T(f.w);
+                    } else {
+                        const double2 d0 = reinterpret_cast<const double2*>(rp)[0], d1 = reinterpret_cast<const double2*>(rp)[1];
+                        v[k][0] = T(d0.x); v[k][1] = T(d0.y); v[k][2] = T(d1.x); v[k][3] = T(d1.y);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + k * THREADS;
+                if (e < total4) {
+                    const int it = e / count4;
+                    T* img = images + it * image_stride;
+                    const uint32_t mm[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        T x = v[k][c];
+                        if (canon) x = T(0) + x;  // the reference's zero-init + add_grades_from copy: 0.0 + x
+                        if (mm[c] >> 31) x = -x;  // a folded Negation / Reverse / GradeInvolution of this grade
+                        img[(mm[c] >> 16) & 0x7fffu] = x;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const int total = nitems * count;
+    for (int e0 = tid; e0 < total; e0 += THREADS * U) {
+        uint32_t m[U];
+        T v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + k * THREADS;
+            m[k] = e < total ? map[e % count] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + k * THREADS;
+            v[k] = e < total ? src[int64_t(e / count) * stride + (m[k] & 0xffffu)] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + k * THREADS;
+            if (e < total) {
+                T x = v[k];
+                if (canon) x = T(0) + x;
+                if (m[k] >> 31) x = -x;
+                images[(e / count) * image_stride + ((m[k] >> 16) & 0x7fffu)] = x;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ constexpr int lo_reorder_parity(int a, int b) {
+    // parity of #{(p,q): p in a, q in b, p > q} for 4-bit a, b
+    int par = 0;
+    for (int p = 1; p < 4; ++p)
+        if ((a >> p) & 1)
+            for (int q = 0; q < p; ++q) par ^= (b >> q) & 1;
+    return par;
+}
+
+template <typename T>
+__device__ __forceinline__ T fma_t(T a, T b, T c);
+template <>
+__device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <>
+__device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- 16x16 block product, generic (used for f64): 256 scalar FMAs with folded signs ----------
+template <typename T, bool ODD>
+__device__ __forceinline__ void gp_block16(const T (&A)[16], const T (&B)[16], T (&C)[16]) {
+#pragma unroll
+    for (int al = 0; al < 16; ++al) {
+#pragma unroll
+        for (int bl = 0; bl < 16; ++bl) {
+            const int neg = lo_reorder_parity(al, bl) ^ (ODD ? (__builtin_popcount(bl) & 1) : 0);
+            C[al ^ bl] = neg ? fma_t<T>(-A[al], B[bl], C[al ^ bl]) : fma_t<T>(A[al], B[bl], C[al ^ bl]);
+        }
+    }
+}
+
+// ---- 16x16 block product, f32: 128 v_pk_fma_f32, no operand shuffles ---------------------------
+// Accumulator pair j holds C[2j], C[2j+1].  For the term with left component a, the low half
+// needs B[a ^ 2j] and the high half B[a ^ 2j ^ 1]: the two halves of ONE B pair, swapped when a
+// is odd; A[a] is one half of an A pair, broadcast.  op_sel / op_sel_hi pick the halves and
+// neg_lo / neg_hi carry the compile-time signs, so every FMA is a single instruction.
+
+template <int X, int NL, int NH>
+__device__ __forceinline__ void pk_fma_sel(float2v& c, const float2v& a, const float2v& b) {
+    if constexpr (X == 0 && NL == 0 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 1 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 0 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 0 && NL == 1 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 0 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 1 && NH == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else if constexpr (X == 1 && NL == 0 && NH == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <bool ODD, int IDX>
+__device__ __forceinline__ void gp_block16_pk(const float2v (&A2)[8], const float2v (&B2)[8], float2v (&C2)[8]) {
+    if constexpr (IDX < 128) {
+        constexpr int a = IDX >> 3, j = IDX & 7, c0 = 2 * j;
+        constexpr int b_lo = a ^ c0, b_hi = a ^ c0 ^ 1;
+        constexpr int nl = lo_reorder_parity(a, b_lo) ^ (ODD ? (__builtin_popcount(b_lo) & 1) : 0);
+        constexpr int nh = lo_reorder_parity(a, b_hi) ^ (ODD ? (__builtin_popcount(b_hi) & 1) : 0);
+        pk_fma_sel<(a & 1), nl, nh>(C2[j], A2[a >> 1], B2[b_lo >> 1]);
+        gp_block16_pk<ODD, IDX + 1>(A2, B2, C2);
+    }
+}
+
+// one a_hi step for a lane: load the blocks, apply the block sign, 256 multiply-adds
+template <typename T>
+struct BlockStep;
+
+template <>
+struct BlockStep<float> {
+    float2v C2[8];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) C2[i] = float2v{0.f, 0.f};
+    }
+    template <bool ODD>
+    __device__ __forceinline__ void step(const float* As, const float* Bs, int a_hi, int b_hi, float sgn) {
+        const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
+        const float4v* ap = reinterpret_cast<const float4v*>(As + (a_hi << 4));
+        const float4v* bp = reinterpret_cast<const float4v*>(Bs + (b_hi << 4));
+        float2v A2[8], B2[8];
+        const float2v s2 = float2v{sgn, sgn};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v va = ap[q ^ sa];
+            const float4v vb = bp[q ^ sb];
+            A2[2 * q] = float2v{va.x, va.y};
+            A2[2 * q + 1] = float2v{va.z, va.w};
+            B2[2 * q] = float2v{vb.x, vb.y} * s2;
+            B2[2 * q + 1] = float2v{vb.z, vb.w} * s2;
+        }
+        gp_block16_pk<ODD, 0>(A2, B2, C2);
+    }
+    __device__ __forceinline__ float get(int i) const { return (i & 1) ? C2[i >> 1].y : C2[i >> 1].x; }
+};
+
+template <>
+struct BlockStep<double> {
+    double C[16];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) C[i] = 0.0;
+    }
+    template <bool ODD>
+    __device__ __forceinline__ void step(const double* As, const double* Bs, int a_hi, int b_hi, double sgn) {
+        const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
+        // a "quad" is 4 components = two 16-byte halves for f64
+        const double2v* ap = reinterpret_cast<const double2v*>(As + (a_hi << 4));
+        const double2v* bp = reinterpret_cast<const double2v*>(Bs + (b_hi << 4));
+        double A[16], B[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2v a0 = ap[2 * (q ^ sa)], a1 = ap[2 * (q ^ sa) + 1];
+            const double2v b0 = bp[2 * (q ^ sb)], b1 = bp[2 * (q ^ sb) + 1];
+            A[4 * q + 0] = a0.x; A[4 * q + 1] = a0.y; A[4 * q + 2] = a1.x; A[4 * q + 3] = a1.y;
+            B[4 * q + 0] = b0.x * sgn; B[4 * q + 1] = b0.y * sgn; B[4 * q + 2] = b1.x * sgn; B[4 * q + 3] = b1.y * sgn;
+        }
+        gp_block16<double, ODD>(A, B, C);
+    }
+    __device__ __forceinline__ double get(int i) const { return C[i]; }
+};
+
+template <typename T, bool DEGENERATE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int n = p.n;
+    const int N = 1 << n;
+    const int hbits = n - 4;
+    const int LPI = 1 << hbits;                   // lanes per item
+    const int IPB = THREADS >> hbits;             // items per group (>= 1)
+    const int item_stride = 2 * N + (IPB > 1 ? 4 : 0);  // +16 B: de-phase the items' A broadcasts
+    const int tid = threadIdx.x;
+    const T zero = T(0);
+    const int64_t num_groups = (p.batch + IPB - 1) / IPB;
+
+    const int it = tid >> hbits;
+    const int c_hi = tid & (LPI - 1);
+    int32_t om[16];  // where this lane's 16 results go in the graded row (the same for every group)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) om[i] = p.out_map[(c_hi << 4) + i];
+
+    // persistent workgroups: each walks the groups blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (int64_t grp = blockIdx.x; grp < num_groups; grp += gridDim.x) {
+        const int64_t item0 = grp * IPB;
+        const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+        // ---- both operands of every item of the group into LDS, in bitmask order ----
+        {
+            if (!p.left_full || !p.right_full) {
+                for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
+                __syncthreads();
+            }
+            stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, nitems, tid);
+            stage_operands<T, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+        }
+        __syncthreads();
+
+        if (it < nitems) {
+            const T* As = smem + it * item_stride;
+            const T* Bs = As + N;
+            BlockStep<T> acc;
+            acc.init();
+
+            // Two passes: first the A blocks with |a_hi| even, then those with |a_hi| odd -- each
+            // pass has ONE straight-line body (the sign pattern of the 16x16 block depends on that
+            // parity), so the accumulators never cross a branch.  a_hi = 2i + (parity(i) ^ pass).
+            auto one_step = [&](auto odd_tag, int a_hi) {
+                constexpr bool ODD = decltype(odd_tag)::value;
+                // wave-uniform part of the block sign
+                uint32_t sp = uint32_t(a_hi) >> 1;
+                sp ^= sp >> 1;
+                sp ^= sp >> 2;
+                sp ^= sp >> 4;
+                sp ^= sp >> 8;
+                const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+                const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                    __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+                // lane part
+                const uint32_t sbit = (u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u;
+                T sgn = sbit ? T(-1) : T(1);
+                if (DEGENERATE) {
+                    if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) sgn = zero;
+                }
+                acc.template step<ODD>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
+            };
+            const int half = LPI >> 1;
+            for (int i = 0; i < half; ++i) one_step(std::false_type{}, (i << 1) | (__builtin_popcount(uint32_t(i)) & 1));
+            for (int i = 0; i < half; ++i) one_step(std::true_type{}, (i << 1) | ((__builtin_popcount(uint32_t(i)) & 1) ^ 1));
+
+            // ---- scatter the 16 accumulators to their positions in the graded row ----
+            T* orow = p.out + (item0 + it) * p.out_stride;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int32_t off = om[i];
+                if (off >= 0) orow[off] = p.beta ? orow[off] + acc.get(i) : acc.get(i);
+            }
+        }
+        __syncthreads();  // the LDS image is rewritten by the next group
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Product arm, dense geometric product on the matrix cores (f32, n >= 10).
+//
+// With lo = 5 bits (blocks of 32) the per-item product is, for every A block a_hi,
+//     C[c_lo][c_hi] += sum_k  M[c_lo][k] * Bs[k][c_hi],      k = b_lo,
+//     M[i][k]  = s_lo(i^k, k) (-1)^(|a_hi| |k|) A[a_hi][i ^ k]             (32 x 32, built on the fly)
+//     Bs[k][j] = s_blk(a_hi, b_hi(j)) B[b_hi(j)][k],   b_hi(j) = a_hi ^ c_hi(j)  (32 x 32 columns)
+// i.e. a genuine 32x32x32 GEMM tile per (a_hi, 32 result columns): 16 v_mfma_f32_32x32x2_f32.
+// The MFMA A operand of lane l is M[i = l&31][k = 2s + (l>>5)]: one ds_read_b32 of the A block
+// at a lane-permuted position (conflict-free: the 32 lanes of a half-wave read a permutation
+// of the block's 32 dwords) and one sign flip with a lane-constant mask.  The B operand of
+// lane l is Bs[k = 2s + (l>>5)][j = l&31]: the 16 components of its own B block with index
+// parity (l>>5), stored de-interleaved so that they are 64 contiguous bytes (4 ds_read_b128,
+// quads rotated by (x>>1)&7 per block x: 16 lanes reading the same logical quad of 16 blocks
+// hit 16 different bank quads), times the block sign.  f32 MFMA accumulates like a k-ordered
+// fmaf chain, at the vector FMA rate, without occupying the vector ALUs.
+// Requires the low FIVE basis vectors to square to +1.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ constexpr int lo5_reorder_parity(int a, int b) {
+    int par = 0;
+    for (int p = 1; p < 5; ++p)
+        if ((a >> p) & 1)
+            for (int q = 0; q < p; ++q) par ^= (b >> q) & 1;
+    return par;
+}
+
+// LDS position of blade m inside the B image: block x = m >> 5; inside it the components are
+// de-interleaved by the parity of k = m & 31 (even k first), 8 quads rotated by (x >> 1) & 7.
+__device__ __forceinline__ int mfma_b_pos(int m) {
+    const int x = m >> 5, k = m & 31;
+    const int lq = ((k & 1) << 2) | (k >> 3);   // logical quad: parity * 4 + (k/2)/4
+    return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
+}
+
+template <bool DEGENERATE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int n = p.n;
+    const int N = 1 << n;
+    const int hbits = n - 5;
+    const int H = 1 << hbits;                     // number of 32-blocks
+    const int WPI = H >> 5;                       // waves per item (32 result columns each)
+    const int IPB = (THREADS >> 6) / WPI;         // items per block (>= 1)
+    const int item_stride = 2 * N;
+    const int tid = threadIdx.x;
+    const int64_t item0 = int64_t(blockIdx.x) * IPB;
+    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+
+    // ---- stage both operands in bitmask order (B de-interleaved and quad-rotated) ----
+    if (!p.left_full || !p.right_full) {
+        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
+        __syncthreads();
+    }
+    {
+        stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, nitems, tid);
+        stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int it = wave / WPI, tile = wave - it * WPI;
+    if (it < nitems) {
+        const float* As = smem + it * item_stride;
+        const float* Bs = As + N;
+        const int i = lane & 31, h = lane >> 5;
+        const int c_hi = (tile << 5) | i;
+
+        // lane constants: sign masks of the A operand for both parities of |a_hi|, and the
+        // byte offset of A[i ^ k] inside a block, for k = 2s + h
+        uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
+        uint32_t aoff[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int k = 2 * s2 + h;
+            const int a_lo = i ^ k;
+            int par = 0;
+            for (int pp = 1; pp < 5; ++pp)
+                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+            amask[s2] = uint32_t(par) << 31;
+            aoff[s2] = uint32_t(a_lo) << 2;
+        }
+
+        // one accumulator chain per wave: a dependent f32 MFMA issues back to back (measured: a
+        // second, independent chain changes nothing; what costs is the LDS -> VGPR operand traffic,
+        // about 11 cycles of matrix-pipe time per ds_read_b32 and 24 per ds_read_b128 --
+        // tools/microbench/mfma_rate.hip)
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
+        auto one_step = [&](int a_hi) {
+            // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
+            uint32_t sp = uint32_t(a_hi) >> 1;
+            sp ^= sp >> 1;
+            sp ^= sp >> 2;
+            sp ^= sp >> 4;
+            sp ^= sp >> 8;
+            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+            const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
+            float bscale = 1.f;
+            if (DEGENERATE) {
+                if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
+            }
+            const int x = a_hi ^ c_hi;
+            const int rot = (x >> 1) & 7;
+            const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 5));
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v v = bp[((h << 2) | q) ^ rot];
+                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+            }
+            const uint32_t abase = uint32_t(a_hi) << 7;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                float a = *reinterpret_cast<const float*>(As_b + abase + aoff[s2]);
+                a = __uint_as_float(__float_as_uint(a) ^ amask[s2]);
+                float b = __uint_as_float(__float_as_uint(bv[s2]) ^ bmask);
+                if (DEGENERATE) b *= bscale;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        };
+        const int half = H >> 1;
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)  // (-1)^(|a_hi| |k|) for odd |a_hi|: flip where |k| is odd, k = 2 s2 + h
+            amask[s2] ^= uint32_t((__builtin_popcount(uint32_t(s2)) + h) & 1) << 31;
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+
+        // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
+        float* orow = p.out + (item0 + it) * p.out_stride;
+        const int32_t* om = p.out_map + (c_hi << 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int32_t off = om[c_lo];
+            if (off >= 0) orow[off] = p.beta ? orow[off] + acc[r] : acc[r];
+        }
+    }
+}
+
+}  // namespace gaast

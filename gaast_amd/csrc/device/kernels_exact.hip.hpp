@@ -1,0 +1,121 @@
+// kernels_exact.hip.hpp -- elementwise arms (GradedObj copy, sign flips, scalar unary) and the exact CSR product
+// Included through kernels.hip.hpp.
+#pragma once
+#include "kernels_common.hip.hpp"
+
+namespace gaast {
+
+// ------------------------------------------------------------------------------------------
+// element-wise arms (HBM-bound; one thread per (item, mapped component))
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_axpy_map(T* __restrict__ res, int64_t res_stride,
+                                                  const T* __restrict__ in, int64_t in_stride,
+                                                  const uint32_t* __restrict__ map, int n_map,
+                                                  int64_t batch) {
+    const int64_t total = batch * n_map;
+    for (int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t item = idx / n_map;
+        const int j = int(idx - item * n_map);
+        const uint32_t m = map[j];
+        T* r = res + item * res_stride + (m & 0xffffu);
+        *r = *r + in[item * in_stride + (m >> 16)];  // graded.rs:74  `*r = *r + i`
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_flip(T* __restrict__ res, int64_t res_stride,
+                                              const uint32_t* __restrict__ offs, int n_offs,
+                                              int64_t batch) {
+    const int64_t total = batch * n_offs;
+    for (int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t item = idx / n_offs;
+        const int j = int(idx - item * n_offs);
+        T* r = res + item * res_stride + offs[j];
+        *r = -*r;  // graded.rs:63
+    }
+}
+
+enum : int { SUNARY_INV = 0, SUNARY_SQRT = 1 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scalar_unary(T* __restrict__ res, int64_t res_stride,
+                                                      int off, int op, int64_t batch) {
+    for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < batch;
+         item += int64_t(gridDim.x) * blockDim.x) {
+        T* r = res + item * res_stride + off;
+        const T s = *r;
+        // eval.rs:106-109; IEEE division and sqrt are correctly rounded on gfx950 for both types
+        *r = op == SUNARY_INV ? T(1) / s : (sizeof(T) == 8 ? T(__builtin_sqrt(double(s)))
+                                                           : T(__builtin_sqrtf(float(s))));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Product arm, exact: the comp-mul list grouped by result component (CSR by output), the
+// entries of one output kept in the reference's order, so every output component sees the
+// very same sequence of roundings as eval.rs:77-83.
+//
+// Block = `items` batch items; operand rows are staged in LDS with coalesced loads, then
+// one thread per (item, output row) walks its entry list.  Entry = left offset | right
+// offset << 16 (offsets into the staged rows) with the coefficient in a parallel array.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct CsrArgs {
+    const T* left;
+    const T* right;
+    T* out;
+    int64_t left_stride, right_stride, out_stride;  // elements; 0 = broadcast row
+    int left_len, right_len;                        // row lengths staged in LDS
+    int canon_left, canon_right;                    // operand is a raw input: apply 0.0 + x
+    const uint32_t* row_start;                      // n_rows + 1
+    const uint32_t* row_out;                        // output offset of each row
+    const uint32_t* entries;
+    const T* coeff;
+    int n_rows;
+    int beta;                                       // 1: accumulate into out; 0: out is fresh
+    int64_t batch;
+    int items;                                      // items per block
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ls = reinterpret_cast<T*>(smem_raw);
+    T* rs = ls + int64_t(p.items) * p.left_len;
+    const int64_t item0 = int64_t(blockIdx.x) * p.items;
+    const int nitems = int(p.batch - item0 < p.items ? p.batch - item0 : p.items);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    // stage operand rows: consecutive threads read consecutive elements of consecutive rows
+    const T zero = T(0);
+    for (int i = tid; i < nitems * p.left_len; i += nthr) {
+        const int it = i / p.left_len, c = i - it * p.left_len;
+        T v = p.left[(item0 + it) * p.left_stride + c];
+        ls[i] = p.canon_left ? zero + v : v;  // init_null_mv + add_grades_from: 0.0 + x
+    }
+    for (int i = tid; i < nitems * p.right_len; i += nthr) {
+        const int it = i / p.right_len, c = i - it * p.right_len;
+        T v = p.right[(item0 + it) * p.right_stride + c];
+        rs[i] = p.canon_right ? zero + v : v;
+    }
+    __syncthreads();
+
+    for (int w = tid; w < nitems * p.n_rows; w += nthr) {
+        const int it = w / p.n_rows, row = w - it * p.n_rows;
+        T* o = p.out + (item0 + it) * p.out_stride + p.row_out[row];
+        T acc = p.beta ? *o : zero;
+        const T* l = ls + int64_t(it) * p.left_len;
+        const T* r = rs + int64_t(it) * p.right_len;
+        const uint32_t e1 = p.row_start[row + 1];
+        for (uint32_t e = p.row_start[row]; e < e1; ++e) {
+            const uint32_t lr = p.entries[e];
+            acc = acc + (l[lr & 0xffffu] * r[lr >> 16]) * p.coeff[e];  // eval.rs:82
+        }
+        *o = acc;
+    }
+}
+
+}  // namespace gaast

@@ -1,0 +1,419 @@
+// kernels_spinor.hip.hpp -- opt-in: the geometric product through the matrix representation
+// Included through kernels.hip.hpp.
+#pragma once
+#include "kernels_common.hip.hpp"
+
+namespace gaast {
+
+// ------------------------------------------------------------------------------------------
+// OPT-IN fast path (GAAST_FLAG_SPINOR_GEMM): the geometric product of a non-degenerate algebra
+// with n = 12 through its matrix representation -- 16x fewer multiply-adds than the bilinear
+// contraction, all of them on the matrix cores.  NOT the reference's algorithm: same result in
+// exact arithmetic, different roundings (norm-wise error bound), so it is never
+// selected unless the host asks for it.
+//
+// Cl(p,q), p+q = 12, over the complex numbers is the algebra of 64 x 64 matrices.  With the
+// Jordan-Wigner generators gamma_{2j} = Z..Z X_j, gamma_{2j+1} = Z..Z Y_j (times i for the vectors
+// that square to -1), a blade e_S is i^k(S) X^x(S) Z^z(S), a Pauli string; S -> (x, z) is a
+// bijection onto 6-bit pairs.  (X^x Z^z)[c^x][c] = (-1)^|c & z|, so for the multivector A
+//     M_A[c ^ x][c] = sum_z (-1)^|c & z| * i^k(x,z) A_{S(x,z)}       -- a Walsh-Hadamard transform
+// over z of row x of the re-indexed components; the product is C = M_A M_B (complex 64^3
+// GEMM = 3 real ones = 384 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
+// transform of the skewed diagonals of C gives the components back.
+//
+// Workgroup = 256 threads, persistent over items.  LDS: four 64 x 65 f32 planes (A re/im, B re/im;
+// the +1 column makes the row-wise and the XOR-skewed column-wise accesses conflict-free, and
+// 4160 words = 65 x 256 B lets one ds_read2st64_b32 fetch re and im together).
+//   1. scatter the graded rows into W[x][z] from registers (16-bit table entries, branch-free)
+//   2. 256 threads = 256 row transforms (2 operands x re/im x 64 rows), 64 values in registers,
+//      written back in place: S_A[x][c] = M_A[c^x][c]; S_B[x][r] = M_B[r][r^x] -- the shift by x
+//      of B's transform is a sign (-1)^|x&z| on its input, folded into the right operand's table --
+//      so both MFMA operand gathers hit 32 distinct banks
+//   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair two LDS reads and THREE MFMAs
+//      (X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y), operands of the next
+//      step read while the current MFMAs run
+//   4. C tiles go back to LDS skewed (by r, conflict-free); two threads per row fold and transform 32 points each;
+//      every transformed value is the component of one blade (real part for even k, imaginary
+//      for odd k), gathered in row order so that the stores to HBM are coalesced.
+// The operands of the next item are loaded into registers during steps 2-4.
+// Measured (profiles/r01_r12s_*): 32 M products/s at B = 65536, 8.7x the contraction kernel.
+// ------------------------------------------------------------------------------------------
+struct SpinorArgs {
+    const float* left;
+    const float* right;
+    float* out;
+    int64_t left_stride, right_stride, out_stride;
+    // 4096 16-bit entries each, indexed by ROW OFFSET (two per word).
+    //  operands: bit 0 = negate (folded unary signs, i^2, the right operand's shift), bit 1 = plane
+    //            (0 real, 1 imaginary: parity of k), bits [14:2] = x*65+z, i.e. entry & 0x7ffc is the byte
+    //            offset inside a plane; offsets that hold nothing point at a padding word (x*65+z = 64)
+    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = plane*4160 + x*65+z
+    const uint16_t* left_map;
+    const uint16_t* right_map;
+    const uint16_t* out_map;
+    int left_len, right_len;
+    int out_full;
+    int left_full, right_full;
+    int canon_left, canon_right;
+    int beta;
+    int64_t batch;
+};
+
+template <int N>
+__device__ __forceinline__ void wht(float (&v)[N]) {
+#pragma unroll
+    for (int hlf = 1; hlf < N; hlf <<= 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if ((i & hlf) == 0) {
+                const float a = v[i], b = v[i | hlf];
+                v[i] = a + b;
+                v[i | hlf] = a - b;
+            }
+        }
+    }
+}
+
+// Persistent workgroups (grid = resident blocks): the three tables live in registers for the
+// whole launch and the operands of the NEXT item are fetched while the matrix cores work on the
+// current one, so no phase waits on HBM latency.
+__global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int D = 64, LD = 65, P = D * LD;  // plane = 64 rows of 65
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    // entry e = tid + 256 u; two 16-bit entries per register (u = 2w, 2w+1)
+    uint32_t lm[8], rm[8], om[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
+        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
+        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    float va[16], vb[16];
+    const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
+    auto fetch = [&](int64_t item) {
+        const float* lrow = p.left + item * p.left_stride + tid;
+        const float* rrow = p.right + item * p.right_stride + tid;
+        if (rows_full) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                va[u] = lrow[256 * u];
+                vb[u] = rrow[256 * u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + 256 * u;
+                va[u] = e < p.left_len ? lrow[256 * u] : 0.f;
+                vb[u] = e < p.right_len ? rrow[256 * u] : 0.f;
+            }
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+
+    for (; item < p.batch; item += gridDim.x) {
+        // keep the packed tables packed: without this the decoded fields of all 48 entries are hoisted
+        // out of the loop and the kernel spills
+#pragma unroll
+        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        // ---- 1. graded rows -> W[x][z], split into real / imaginary planes by the phase i^k ----
+        if (!p.left_full || !p.right_full) {
+            for (int i = tid; i < 4 * P; i += 256) smem[i] = 0.f;
+            __syncthreads();
+        }
+        {
+            // branch-free: one write of (re, im) = (a, 0) or (0, a) per component
+            auto put = [&](float* planes, uint32_t e, float a, int canon) {
+                if (canon) a = 0.f + a;
+                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
+                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
+                const bool im = (e & 2u) != 0;
+                q[0] = im ? 0.f : a;
+                q[P] = im ? a : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + 2 * P, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+        // operands of the next item: in flight during the transforms and the GEMM
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+
+        // ---- 2. Walsh-Hadamard transform of every row: thread = (operand, plane, x) ----
+        {
+            float* row = smem + (tid >> 6) * P + (tid & 63) * LD;
+            float v[64];
+#pragma unroll
+            for (int z = 0; z < 64; ++z) v[z] = row[z];
+            wht<64>(v);
+            // S_A[x][c] = M_A[c^x][c] = T_x[c].  S_B[x][r] = M_B[r][r^x] = T_x[r^x]: a shift of the
+            // transform's index by x is a sign (-1)^|x&z| on its input, which the right operand's table
+            // already carries, so both operands are written back in place.
+#pragma unroll
+            for (int c = 0; c < 64; ++c) row[c] = v[c];
+        }
+        __syncthreads();
+
+        // ---- 3. complex 64 x 64 x 64 product on the matrix cores ----
+        const int i = lane & 31, h = lane >> 5;
+        const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
+        // (Ar + i Ai)(Br + i Bi) with three real products: X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi);
+        // Re = X - Y, Im = Z - X - Y
+        float16v gx, gy, gz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gx[r] = 0.f;
+            gy[r] = 0.f;
+            gz[r] = 0.f;
+        }
+        {
+            const float* Are = smem;
+            const float* Aim = smem + P;
+            const float* Bre = smem + 2 * P;
+            const float* Bim = smem + 3 * P;
+            (void)Are; (void)Aim; (void)Bre; (void)Bim;
+            const uint32_t ra = uint32_t(r0 + i), cb = uint32_t(c0 + i);
+            const uint32_t lds0 = uint32_t(uintptr_t(smem));
+            const uint32_t row_bytes = LD * 4;
+            // M_A[ra][k] = S_A[ra ^ k][k], M_B[k][cb] = S_B[k ^ cb][k].  Hand-scheduled: the operands
+            // of step s2+1 are read (re and im planes with one ds_read2st64) while the three MFMAs of
+            // step s2 run; byte address = (row * 65 + k) * 4 with a 24-bit multiply-add.
+            float2v av[2], bv[2];
+            uint32_t k4 = lds0 + 4u * uint32_t(h), kk = uint32_t(h);
+            auto issue = [&](float2v& a, float2v& b) {
+                uint32_t aa, ab;
+                // the running k (and 4k + base) are advanced inside the asm so that the 32 unrolled
+                // values are not precomputed outside the item loop (and spilled)
+                asm volatile("v_xor_b32 %0, %4, %2\n\tv_xor_b32 %1, %5, %2\n\t"
+                             "v_mad_u32_u24 %0, %0, %6, %3\n\tv_mad_u32_u24 %1, %1, %6, %3\n\t"
+                             "v_add_u32 %2, 2, %2\n\tv_add_u32 %3, 8, %3"
+                             : "=&v"(aa), "=&v"(ab), "+v"(kk), "+v"(k4) : "v"(ra), "v"(cb), "s"(row_bytes));
+                asm volatile("ds_read2st64_b32 %0, %1 offset1:65" : "=v"(a) : "v"(aa));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:130 offset1:195" : "=v"(b) : "v"(ab));
+            };
+            issue(av[0], bv[0]);
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float2v& a = av[s2 & 1];
+                float2v& b = bv[s2 & 1];
+                asm volatile("" : "+v"(a), "+v"(b));   // the reads above have landed: values are live from here
+                if (s2 < 31) issue(av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, gz, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // every wave is done reading A and B
+
+        // ---- 4. C back to LDS, skewed: S_C[r ^ c][r] = C[r][c] (reusing the A planes).  Indexing the
+        // diagonal x = r ^ c by r (not c) keeps the 32 lanes of a store on 32 banks; the transform of a
+        // row shifted by x is the wanted one times (-1)^|x&z|, a sign the result table carries. ----
+        {
+            const int c = c0 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                smem[(rr ^ c) * LD + rr] = gx[r] - gy[r];
+                smem[P + (rr ^ c) * LD + rr] = gz[r] - gx[r] - gy[r];
+            }
+        }
+        __syncthreads();
+        // inverse transform in place: V[x][z] = 2^-6 sum_c (-1)^|c & z| S_C[x][c]
+        // two threads per row (adjacent lanes): thread hb folds the halves with sign (-1)^hb, a 32-point
+        // transform then gives the outputs z = j + 32 hb
+        {
+            const int hb = tid & 1;
+            float* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
+            const float sg = hb ? -1.0f / 64.0f : 1.0f / 64.0f;
+            float v[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = row[c] * (1.0f / 64.0f) + row[c + 32] * sg;
+            wht<32>(v);
+#pragma unroll
+            for (int z = 0; z < 32; ++z) row[z + 32 * hb] = v[z];   // same wave as the partner's reads: ordered
+        }
+        __syncthreads();
+        // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3; rows written in order
+        {
+            float* orow = p.out + item * p.out_stride + tid;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t eo = entry(om, u);
+                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
+                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[256 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
+                }
+            }
+        }
+        __syncthreads();  // the planes are free for the next item
+    }
+}
+
+// Same algorithm for the smaller even dimensions: n = 8 (16 x 16 matrices, v_mfma_f32_16x16x4_f32)
+// and n = 10 (32 x 32, v_mfma_f32_32x32x2_f32); odd n runs as the subalgebra of n + 1.  One WAVE per
+// item (64-thread workgroups, persistent), so the phases need no cross-wave barrier, and the four
+// planes of an item are 5 KB / 17 KB of LDS.  Plane stride = a multiple of 64 words (re/im pairs by
+// ds_read2st64).  Table formats as in SpinorArgs with 65 -> D + 1 and 4160 -> the plane stride.
+template <int M>
+__global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int D = 1 << M, LD = D + 1, P = D * LD;
+    constexpr int PS = (P + 63) / 64 * 64;
+    constexpr int NE = D * D, EPL = NE / 64, RPL = 4 * D / 64;
+    using acc_t = typename std::conditional<M == 4, float4v, float16v>::type;
+    constexpr int NACC = M == 4 ? 4 : 16;
+    const int lane = threadIdx.x;
+
+    uint32_t lm[EPL / 2], rm[EPL / 2], om[EPL / 2];
+#pragma unroll
+    for (int w = 0; w < EPL / 2; ++w) {
+        lm[w] = uint32_t(p.left_map[lane + 128 * w]) | (uint32_t(p.left_map[lane + 128 * w + 64]) << 16);
+        rm[w] = uint32_t(p.right_map[lane + 128 * w]) | (uint32_t(p.right_map[lane + 128 * w + 64]) << 16);
+        om[w] = uint32_t(p.out_map[lane + 128 * w]) | (uint32_t(p.out_map[lane + 128 * w + 64]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[EPL / 2], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    float va[EPL], vb[EPL];
+    const bool rows_full = p.left_len == NE && p.right_len == NE;
+    auto fetch = [&](int64_t item) {
+        const float* lrow = p.left + item * p.left_stride + lane;
+        const float* rrow = p.right + item * p.right_stride + lane;
+        if (rows_full) {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                va[u] = lrow[64 * u];
+                vb[u] = rrow[64 * u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int e = lane + 64 * u;
+                va[u] = e < p.left_len ? lrow[64 * u] : 0.f;
+                vb[u] = e < p.right_len ? rrow[64 * u] : 0.f;
+            }
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+
+    for (; item < p.batch; item += gridDim.x) {
+#pragma unroll
+        for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        if (!p.left_full || !p.right_full) {
+            for (int i = lane; i < 4 * PS; i += 64) smem[i] = 0.f;
+            __syncthreads();
+        }
+        {
+            auto put = [&](float* planes, uint32_t e, float a, int canon) {
+                if (canon) a = 0.f + a;
+                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
+                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
+                const bool im = (e & 2u) != 0;
+                q[0] = im ? 0.f : a;
+                q[PS] = im ? a : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + 2 * PS, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+
+        // row transforms: (operand, plane, x) = 4 D rows over 64 lanes
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int ridx = lane + 64 * j;
+            float* row = smem + (ridx >> M) * PS + (ridx & (D - 1)) * LD;
+            float v[D];
+#pragma unroll
+            for (int z = 0; z < D; ++z) v[z] = row[z];
+            wht<D>(v);
+#pragma unroll
+            for (int c = 0; c < D; ++c) row[c] = v[c];
+        }
+        __syncthreads();
+
+        // complex D x D x D product, three real ones (see k_gp_spinor12)
+        acc_t gx, gy, gz;
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            gx[r] = 0.f;
+            gy[r] = 0.f;
+            gz[r] = 0.f;
+        }
+        const int i = lane & (D - 1);
+        const int kq = lane >> M;                 // M = 4: 0..3 (k = 4 s + kq);  M = 5: 0..1 (k = 2 s + kq)
+        constexpr int KSTEP = 64 / D;             // k values per MFMA
+#pragma unroll
+        for (int s2 = 0; s2 < D / KSTEP; ++s2) {
+            const int k = KSTEP * s2 + kq;
+            const int idx = (i ^ k) * LD + k;     // M_A[i][k] = S_A[i^k][k], M_B[k][i] = S_B[k^i][k]
+            const float are = smem[idx], aim = smem[PS + idx], bre = smem[2 * PS + idx], bim = smem[3 * PS + idx];
+            if constexpr (M == 4) {
+                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(are, bre, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_16x16x4f32(aim, bim, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_16x16x4f32(are + aim, bre + bim, gz, 0, 0, 0);
+            } else {
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, gz, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // C back, diagonals indexed by row: S_C[r ^ c][r] = C[r][c]
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
+            smem[(rr ^ i) * LD + rr] = gx[r] - gy[r];
+            smem[PS + (rr ^ i) * LD + rr] = gz[r] - gx[r] - gy[r];
+        }
+        __syncthreads();
+        // inverse transform: (plane, x, half) = 4 D half-rows over 64 lanes
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int hidx = lane + 64 * j;
+            const int hb = hidx & 1;
+            float* row = smem + (hidx >> (M + 1)) * PS + ((hidx >> 1) & (D - 1)) * LD;
+            const float sc = 1.0f / float(D), sg = hb ? -sc : sc;
+            float v[D / 2];
+#pragma unroll
+            for (int c = 0; c < D / 2; ++c) v[c] = row[c] * sc + row[c + D / 2] * sg;
+            wht<D / 2>(v);
+#pragma unroll
+            for (int z = 0; z < D / 2; ++z) row[z + (D / 2) * hb] = v[z];
+        }
+        __syncthreads();
+        {
+            float* orow = p.out + item * p.out_stride + lane;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const uint32_t eo = entry(om, u);
+                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
+                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[64 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace gaast

@@ -201,8 +201,6 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 q.canon_right = s.canon_b;
                 q.beta = s.beta;
                 q.batch = batch;
-                static const int sdbg = std::getenv("GAAST_DEBUG_DENSE_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_DENSE_SKIP")) : 0;
-                q.debug_skip = sdbg;
                 using KernS = void (*)(SpinorArgs);
                 const int m = s.use_spinor;
                 const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
@@ -249,8 +247,6 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.zero_hi = s.zero_hi;
         p.beta = s.beta;
         p.batch = batch;
-        static const int ddbg = std::getenv("GAAST_DEBUG_DENSE_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_DENSE_SKIP")) : 0;
-        p.debug_skip = ddbg;
         if (s.use_mfma) {
             if constexpr (std::is_same<T, float>::value) {
                 const int wpi = 1 << (n - 10);                 // waves per item
@@ -375,8 +371,6 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     p.out_len = int(plan.out_layout.row_len);
     p.out_base = s.fused_out_base;
     p.batch = batch;
-    static const int dbg = std::getenv("GAAST_DEBUG_FUSED_SKIP") ? std::atoi(std::getenv("GAAST_DEBUG_FUSED_SKIP")) : 0;
-    p.debug_skip = dbg;
     const size_t lds = (size_t(p.slab) * FUSED_ITEMS + 8) * sizeof(T);
     const int64_t blocks = (batch + FUSED_ITEMS - 1) / FUSED_ITEMS;
     hipLaunchKernelGGL(k_ast_fused<T>, dim3(unsigned(blocks)), dim3(FUSED_THREADS), lds, g_stream, p);
