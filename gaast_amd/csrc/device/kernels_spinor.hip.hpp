@@ -54,6 +54,7 @@ struct SpinorArgs {
     int left_len, right_len;
     int out_full;
     int left_full, right_full;
+    int has_alpha;           // one-plane kernel: alpha' = e_5 (see spinor_basis.hpp)
     int canon_left, canon_right;
     int beta;
     int64_t batch;
@@ -259,6 +260,197 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
             }
         }
         __syncthreads();  // the planes are free for the next item
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// n = 12 with ONE real plane per operand (derivation, numpy prototype and the exhaustive check over
+// signatures: tools/proto/spinor_single_plane.py; index bookkeeping: spinor_basis.hpp).
+//
+// The phase of a blade is i^k, k = 2u + f, and f is linear in the index pair.  In the basis chosen by
+// the host f = x_5 [HAS_ALPHA] ^ z_LAMBIT, so with W[x][z] = (-1)^u A_S and What = WHT_z(W)
+//     M_A[c^x][c] = E(p, sigma q),   p = What[x][c],  q = What[x][c ^ 2^LAMBIT],  sigma = (-1)^(x_5),
+//     E(p, q) = ((p + q) + i (p - q)) / 2
+// -- one transform per row instead of two, half the staging writes, half the LDS (33 KB), and
+//     E(p,q') E(r,s') = (p s' + q' r)/2 + i (p r - q' s')/2
+// is again three real products X = p r, Y = q' s', Z = (p+q')(r+s').  sigma_A sigma_B leaves a factor
+// (-1)^(k_5) on the real part only: the k loop runs k_5 = 0 first, banks Z-X-Y and X-Y, and subtracts
+// the real part of the second half.  Component S(x,z) = (-1)^u Re(i^-f V[x][z]) reads the real or the
+// imaginary plane of C per (row, z_LAMBIT): four threads per row fold ONE plane over bits LAMBIT and
+// the other of {4,5} and transform the remaining 16 points.
+// LAMBIT = -1: lambda = 0 (q = p, every phase of a row is the same).
+// ------------------------------------------------------------------------------------------
+template <int LAMBIT>
+__global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int LD = 65, P = 64 * LD;
+    constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    uint32_t lm[8], rm[8], om[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
+        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
+        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    float va[16], vb[16];
+    const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
+    auto fetch = [&](int64_t item) {
+        const float* lrow = p.left + item * p.left_stride + tid;
+        const float* rrow = p.right + item * p.right_stride + tid;
+        if (rows_full) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                va[u] = lrow[256 * u];
+                vb[u] = rrow[256 * u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + 256 * u;
+                va[u] = e < p.left_len ? lrow[256 * u] : 0.f;
+                vb[u] = e < p.right_len ? rrow[256 * u] : 0.f;
+            }
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+    // sigma of the tile's rows / columns and the sign of the second k half: wave-uniform
+    const uint32_t rho_mask = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;
+    const uint32_t gam_mask = (p.has_alpha && (wave & 1)) ? 0x80000000u : 0u;
+    const float eps2 = p.has_alpha ? -1.f : 1.f;
+
+    for (; item < p.batch; item += gridDim.x) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        // ---- 1. graded rows -> W[x][z], one word per component ----
+        if (!p.left_full || !p.right_full) {
+            for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.f;
+            __syncthreads();
+        }
+        {
+            auto put = [&](float* plane, uint32_t e, float a, int canon) {
+                if (canon) a = 0.f + a;
+                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (e & 0x7ffcu)) = a;
+            };
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + P, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+
+        // ---- 2. one transform per row, two threads per row: fold bit 5 with sign (-1)^hb, 32 points ----
+        {
+            const int hb = tid & 1;
+            float* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
+            const float sg = hb ? -1.f : 1.f;
+            float v[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = row[c] + row[c + 32] * sg;
+            wht<32>(v);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) row[c + 32 * hb] = v[c];   // the partner (adjacent lane) has read already
+        }
+        __syncthreads();
+
+        // ---- 3. the product: X = p r, Y = q' s', Z = (p+q')(r+s'), k_5 = 0 first ----
+        const int i = lane & 31, h = lane >> 5;
+        const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
+        float16v gx, gy, gz, bank_re, bank_im;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gx[r] = 0.f;
+            gy[r] = 0.f;
+            gz[r] = 0.f;
+        }
+        {
+            const float* A = smem;
+            const float* B = smem + P;
+            const uint32_t ra = uint32_t(r0 + i), cb = uint32_t(c0 + i);
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const uint32_t k = uint32_t(2 * s2 + h);
+                const uint32_t ia = (ra ^ k) * LD + k, ib = (cb ^ k) * LD + k;
+                const bool hi = LAMBIT >= 0 && ((2 * s2) & LAM);          // k has the lambda bit: partner below
+                float pa = A[ia], pb = B[ib];
+                float qa = LAMBIT < 0 ? pa : (hi ? A[ia - LAM] : A[ia + LAM]);
+                float qb = LAMBIT < 0 ? pb : (hi ? B[ib - LAM] : B[ib + LAM]);
+                qa = __uint_as_float(__float_as_uint(qa) ^ rho_mask);
+                qb = __uint_as_float(__float_as_uint(qb) ^ gam_mask);
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, pb, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                if (s2 == 15) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bank_re[r] = gz[r] - gx[r] - gy[r];
+                        bank_im[r] = gx[r] - gy[r];
+                        gx[r] = 0.f;
+                        gy[r] = 0.f;
+                        gz[r] = 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading the operand planes
+
+        // ---- 4. C -> LDS, diagonals indexed by row: S[r ^ c][r] = C[r][c]; plane 0 real, plane 1 imaginary ----
+        {
+            const int c = c0 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                smem[(rr ^ c) * LD + rr] = bank_re[r] + eps2 * (gz[r] - gx[r] - gy[r]);
+                smem[P + (rr ^ c) * LD + rr] = bank_im[r] + (gx[r] - gy[r]);
+            }
+        }
+        __syncthreads();
+        // ---- 5. four threads per row: fold the plane that holds this quarter's components ----
+        {
+            constexpr int B1 = LAMBIT == 4 ? 4 : 5, B2 = LAMBIT == 4 ? 5 : 4;   // first fold on the lambda bit
+            const int x = tid >> 2, h1 = (tid >> 1) & 1, h2 = tid & 1;
+            const int xi = p.has_alpha ? (x >> 5) & 1 : 0;
+            const int f = LAMBIT >= 0 ? (xi ^ h1) : xi;
+            const float* q = smem + f * P + x * LD;
+            const float sc = 1.0f / 128.0f;                // 2^-6 of the transform, 1/2 of E E
+            const float s1 = h1 ? -sc : sc, s2f = h2 ? -1.f : 1.f;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float lo = q[j] * sc + q[j | (1 << B1)] * s1;
+                const float hi = q[j | (1 << B2)] * sc + q[j | (1 << B1) | (1 << B2)] * s1;
+                v[j] = lo + hi * s2f;
+            }
+            wht<16>(v);
+            float* o = smem + x * LD + (h1 << B1) + (h2 << B2);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = v[j];      // the four threads of a row are adjacent lanes
+        }
+        __syncthreads();
+        {
+            float* orow = p.out + item * p.out_stride + tid;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t eo = entry(om, u);
+                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
+                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[256 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -13,6 +13,7 @@
 //       bitmask-tiled kernel (re-ordered sums: tolerance, not bit-exact; GAAST_FLAG_EXACT_ORDER
 //       keeps them on the exact kernel).
 #include "plan.hpp"
+#include "spinor_basis.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -291,15 +292,17 @@ struct Lowering {
         return double(nd.n_comp_muls) * 8.0 >= double(uint64_t(1) << (2 * n));
     }
 
-    // blade -> Pauli string i^k X^x Z^z under the Jordan-Wigner generators (kernels.hip.hpp)
+    // blade -> Pauli string i^k X^x Z^z under the Jordan-Wigner generators (kernels_spinor.hip.hpp);
+    // vectors beyond the algebra's dimension (odd n padded to n + 1) square to +1
     void pauli_string(uint32_t blade, uint32_t* x, uint32_t* z, uint32_t* k) const {
         uint32_t px = 0, pz = 0, pk = 0;
-        for (int v = 0; v < d.vec_space_dim; ++v) {
+        for (int v = 0; v < 32 && (blade >> v); ++v) {
             if (!((blade >> v) & 1u)) continue;
             const int j = v >> 1;
             const uint32_t gx = 1u << j;
             const uint32_t gz = (v & 1) ? (1u << (j + 1)) - 1u : (1u << j) - 1u;
-            const uint32_t gk = uint32_t(v & 1) + (d.metric_diag[v] < 0.0 ? 1u : 0u);
+            const bool negative = v < d.vec_space_dim && d.metric_diag[v] < 0.0;
+            const uint32_t gk = uint32_t(v & 1) + (negative ? 1u : 0u);
             pk = (pk + gk + 2u * uint32_t(__builtin_popcount(pz & gx))) & 3u;
             px ^= gx;
             pz ^= gz;
@@ -373,6 +376,51 @@ struct Lowering {
                 packed.resize(map.size() / 2);
                 std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
             };
+            if (m == 6 && !(plan.flags & GAAST_FLAG_NO_MFMA)) {
+                // one real plane per operand (k_gp_spinor12s): indices in the basis of spinor_basis.hpp
+                uint32_t alpha = 0, lam = 0;
+                for (uint32_t blade = 0; blade < (1u << (2 * m)); ++blade) {
+                    uint32_t px, pz, pk;
+                    pauli_string(blade, &px, &pz, &pk);
+                    if (pz == 0 && __builtin_popcount(px) == 1 && (pk & 1u)) alpha |= px;
+                    if (px == 0 && __builtin_popcount(pz) == 1 && (pk & 1u)) lam |= pz;
+                }
+                const SpinorBasis sb = choose_spinor_basis(m, alpha, lam);
+                s.spinor_lam_bit = sb.lam_bit;
+                s.spinor_has_alpha = sb.has_alpha ? 1 : 0;
+                s.use_spinor = 16;   // the one-plane kernel
+                auto build1 = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
+                    // operands: bit 0 = negate, bits [14:2] = x'*65 + z'; result: bit 0 = negate, bit 1 = nothing
+                    // to store, bits [15:2] = x'*65 + z'
+                    const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(D << 2);
+                    std::vector<uint16_t> map(size_t(D) * D, nothing);
+                    size_t count = 0;
+                    for (int k = 0; k <= n; ++k) {
+                        if (!((want >> k) & 1ULL)) continue;
+                        for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
+                            uint32_t px, pz, pk;
+                            pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
+                            const uint32_t x2 = sb.map_x(px), z2 = sb.map_z(pz);
+                            const uint32_t f = (sb.has_alpha ? (x2 >> (m - 1)) & 1u : 0u) ^
+                                               (sb.lam_bit >= 0 ? (z2 >> sb.lam_bit) & 1u : 0u);
+                            if (f != (pk & 1u)) throw std::runtime_error("spinor basis: phase parity mismatch");
+                            uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
+                            if (role != 0) neg ^= uint32_t(__builtin_popcount(x2 & z2) & 1);
+                            map[size_t(lay.offset(k) + i)] = uint16_t((x2 * LD + z2) << 2 | neg);
+                            ++count;
+                        }
+                    }
+                    *full = count == size_t(D) * D;
+                    packed.resize(map.size() / 2);
+                    std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
+                };
+                build1(ll, lmin & ll.mask, flip_l, 0, s.u32_a, &s.left_full);
+                build1(lrr, rmin & lrr.mask, flip_r, 1, s.u32_b, &s.right_full);
+                build1(lr, omin, 0, 2, s.u32_c, &s.out_full);
+                s.name = "product_spinor_gemm[gp n=" + std::to_string(n) + " one-plane lam=" + std::to_string(sb.lam_bit) + "]";
+                touch(res);
+                return;
+            }
             build_map(ll, lmin & ll.mask, flip_l, 0, s.u32_a, &s.left_full);
             build_map(lrr, rmin & lrr.mask, flip_r, 1, s.u32_b, &s.right_full);
             build_map(lr, omin, 0, 2, s.u32_c, &s.out_full);

@@ -228,7 +228,15 @@ def test_dense_n12_basis_blades_exact():
 # ---- opt-in matrix-representation product (GAAST_FLAG_SPINOR_GEMM) ------------------------------
 # Not the reference's summation: equal in exact arithmetic, so the check is the norm-wise bound the
 # header states, |err_S| <= 64 eps |A|_2 |B|_2, against the float64 bitmask convolution.
-SPINOR_METRICS = [[1.0] * 12, [-1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, -1.0]]
+# the second one and the next five cover every case of the one-plane kernel's index basis (spinor_basis.hpp):
+# lambda on bit 5 with / without alpha, lambda on bit 4, lambda = 0 with / without alpha
+SPINOR_METRICS = [[1.0] * 12, [-1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, -1.0],
+                  [-1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0, -1.0, -1.0, 1.0, -1.0, -1.0],      # lam=5, alpha
+                  [1.0, 1.0, -1.0, -1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 1.0, -1.0, -1.0],        # lam=5, no alpha
+                  [1.0, 1.0, -1.0, 1.0, -1.0, -1.0, -1.0, -1.0, 1.0, 1.0, -1.0, 1.0],        # lam=4
+                  [-1.0, 1.0, -1.0, 1.0, 1.0, -1.0, -1.0, 1.0, -1.0, 1.0, 1.0, -1.0],        # lam=-1, alpha
+                  [1.0, -1.0] * 6]                                                            # lam=-1, no alpha
+SPINOR_VARIANTS = {2: "lam=5", 3: "lam=5", 4: "lam=4", 5: "lam=-1", 6: "lam=-1"}
 
 
 @pytest.mark.parametrize("metric", SPINOR_METRICS)
@@ -238,6 +246,9 @@ def test_spinor_gemm_n12_against_bitmask_convolution(metric):
     rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
     got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
     assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    idx = SPINOR_METRICS.index(metric)
+    if idx in SPINOR_VARIANTS:
+        assert any(SPINOR_VARIANTS[idx] in l for l in spec.launches()), spec.launches()
     for i in range(batch):
         A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
         want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
