@@ -7,47 +7,43 @@ namespace gaast {
 
 // ------------------------------------------------------------------------------------------
 // OPT-IN fast path (GAAST_FLAG_SPINOR_GEMM): the geometric product of a non-degenerate algebra
-// with n = 12 through its matrix representation -- 16x fewer multiply-adds than the bilinear
+// (n = 7..12) through its matrix representation -- at n = 12 21x fewer multiply-adds than the bilinear
 // contraction, all of them on the matrix cores.  NOT the reference's algorithm: same result in
 // exact arithmetic, different roundings (norm-wise error bound), so it is never
 // selected unless the host asks for it.
 //
-// Cl(p,q), p+q = 12, over the complex numbers is the algebra of 64 x 64 matrices.  With the
+// Cl(p,q), p+q = 2m, over the complex numbers is the algebra of 2^m x 2^m matrices.  With the
 // Jordan-Wigner generators gamma_{2j} = Z..Z X_j, gamma_{2j+1} = Z..Z Y_j (times i for the vectors
 // that square to -1), a blade e_S is i^k(S) X^x(S) Z^z(S), a Pauli string; S -> (x, z) is a
-// bijection onto 6-bit pairs.  (X^x Z^z)[c^x][c] = (-1)^|c & z|, so for the multivector A
+// bijection onto pairs of m-bit masks.  (X^x Z^z)[c^x][c] = (-1)^|c & z|, so for the multivector A
 //     M_A[c ^ x][c] = sum_z (-1)^|c & z| * i^k(x,z) A_{S(x,z)}       -- a Walsh-Hadamard transform
-// over z of row x of the re-indexed components; the product is C = M_A M_B (complex 64^3
-// GEMM = 3 real ones = 384 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
+// over z of row x of the re-indexed components; the product is C = M_A M_B (a complex GEMM = 3
+// real ones, Gauss: at m = 6, 288 v_mfma_f32_32x32x2_f32 per item instead of 8192); the inverse
 // transform of the skewed diagonals of C gives the components back.
 //
-// Workgroup = 256 threads, persistent over items.  LDS: four 64 x 65 f32 planes (A re/im, B re/im;
-// the +1 column makes the row-wise and the XOR-skewed column-wise accesses conflict-free, and
-// 4160 words = 65 x 256 B lets one ds_read2st64_b32 fetch re and im together).
-//   1. scatter the graded rows into W[x][z] from registers (16-bit table entries, branch-free)
-//   2. 256 threads = 256 row transforms (2 operands x re/im x 64 rows), 64 values in registers,
-//      written back in place: S_A[x][c] = M_A[c^x][c]; S_B[x][r] = M_B[r][r^x] -- the shift by x
-//      of B's transform is a sign (-1)^|x&z| on its input, folded into the right operand's table --
-//      so both MFMA operand gathers hit 32 distinct banks
-//   3. wave w owns the 32 x 32 complex tile (w>>1, w&1): per k-pair two LDS reads and THREE MFMAs
-//      (X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y), operands of the next
-//      step read while the current MFMAs run
-//   4. C tiles go back to LDS skewed (by r, conflict-free); two threads per row fold and transform 32 points each;
-//      every transformed value is the component of one blade (real part for even k, imaginary
-//      for odd k), gathered in row order so that the stores to HBM are coalesced.
-// The operands of the next item are loaded into registers during steps 2-4.
-// Measured (profiles/r01_r12s_*): 32 M products/s at B = 65536, 8.7x the contraction kernel.
+// Common to the kernels below:
+//   * the graded rows are scattered into W[x][z] (rows of 2^m + 1 words: the row-wise and the
+//     XOR-skewed column-wise accesses both hit distinct banks) from registers, through 16-bit
+//     table entries held in registers for the whole launch; persistent workgroups fetch the next
+//     item's rows while the current one is in the transforms and the GEMM;
+//   * transformed rows are written back in place, S_A[x][c] = M_A[c^x][c] and S_B[x][r] = M_B[r][r^x]
+//     -- the index shift by x of B's transform is a sign (-1)^|x&z| on its input, carried by the
+//     right operand's table -- so both MFMA operand gathers are conflict-free;
+//   * C goes back to LDS with its diagonals indexed by row (conflict-free; the shift is a sign in
+//     the result table), is transformed back by several threads per row (fold, then a short
+//     transform), and the result rows are gathered in order so that the stores are coalesced.
 // ------------------------------------------------------------------------------------------
 struct SpinorArgs {
     const float* left;
     const float* right;
     float* out;
     int64_t left_stride, right_stride, out_stride;
-    // 4096 16-bit entries each, indexed by ROW OFFSET (two per word).
+    // 4^m 16-bit entries each, indexed by ROW OFFSET (two per word); D = 2^m, LD = D + 1.
     //  operands: bit 0 = negate (folded unary signs, i^2, the right operand's shift), bit 1 = plane
-    //            (0 real, 1 imaginary: parity of k), bits [14:2] = x*65+z, i.e. entry & 0x7ffc is the byte
-    //            offset inside a plane; offsets that hold nothing point at a padding word (x*65+z = 64)
-    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = plane*4160 + x*65+z
+    //            (two-plane kernels: 0 real, 1 imaginary = parity of k), bits [14:2] = x*LD+z, i.e.
+    //            entry & 0x7ffc is the byte offset inside a plane; offsets that hold nothing point at a
+    //            padding word (x*LD+z = D)
+    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = plane*stride + x*LD+z
     const uint16_t* left_map;
     const uint16_t* right_map;
     const uint16_t* out_map;
@@ -72,194 +68,6 @@ __device__ __forceinline__ void wht(float (&v)[N]) {
                 v[i | hlf] = a - b;
             }
         }
-    }
-}
-
-// Persistent workgroups (grid = resident blocks): the three tables live in registers for the
-// whole launch and the operands of the NEXT item are fetched while the matrix cores work on the
-// current one, so no phase waits on HBM latency.
-__global__ __launch_bounds__(256, 2) void k_gp_spinor12(SpinorArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* smem = reinterpret_cast<float*>(smem_raw);
-    constexpr int D = 64, LD = 65, P = D * LD;  // plane = 64 rows of 65
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-
-    // entry e = tid + 256 u; two 16-bit entries per register (u = 2w, 2w+1)
-    uint32_t lm[8], rm[8], om[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
-        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
-        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
-    }
-    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
-    float va[16], vb[16];
-    const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
-    auto fetch = [&](int64_t item) {
-        const float* lrow = p.left + item * p.left_stride + tid;
-        const float* rrow = p.right + item * p.right_stride + tid;
-        if (rows_full) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                va[u] = lrow[256 * u];
-                vb[u] = rrow[256 * u];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = tid + 256 * u;
-                va[u] = e < p.left_len ? lrow[256 * u] : 0.f;
-                vb[u] = e < p.right_len ? rrow[256 * u] : 0.f;
-            }
-        }
-    };
-    int64_t item = blockIdx.x;
-    if (item < p.batch) fetch(item);
-
-    for (; item < p.batch; item += gridDim.x) {
-        // keep the packed tables packed: without this the decoded fields of all 48 entries are hoisted
-        // out of the loop and the kernel spills
-#pragma unroll
-        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
-        // ---- 1. graded rows -> W[x][z], split into real / imaginary planes by the phase i^k ----
-        if (!p.left_full || !p.right_full) {
-            for (int i = tid; i < 4 * P; i += 256) smem[i] = 0.f;
-            __syncthreads();
-        }
-        {
-            // branch-free: one write of (re, im) = (a, 0) or (0, a) per component
-            auto put = [&](float* planes, uint32_t e, float a, int canon) {
-                if (canon) a = 0.f + a;
-                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
-                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
-                const bool im = (e & 2u) != 0;
-                q[0] = im ? 0.f : a;
-                q[P] = im ? a : 0.f;
-            };
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + 2 * P, entry(rm, u), vb[u], p.canon_right);
-            }
-        }
-        __syncthreads();
-        // operands of the next item: in flight during the transforms and the GEMM
-        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
-
-        // ---- 2. Walsh-Hadamard transform of every row: thread = (operand, plane, x) ----
-        {
-            float* row = smem + (tid >> 6) * P + (tid & 63) * LD;
-            float v[64];
-#pragma unroll
-            for (int z = 0; z < 64; ++z) v[z] = row[z];
-            wht<64>(v);
-            // S_A[x][c] = M_A[c^x][c] = T_x[c].  S_B[x][r] = M_B[r][r^x] = T_x[r^x]: a shift of the
-            // transform's index by x is a sign (-1)^|x&z| on its input, which the right operand's table
-            // already carries, so both operands are written back in place.
-#pragma unroll
-            for (int c = 0; c < 64; ++c) row[c] = v[c];
-        }
-        __syncthreads();
-
-        // ---- 3. complex 64 x 64 x 64 product on the matrix cores ----
-        const int i = lane & 31, h = lane >> 5;
-        const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
-        // (Ar + i Ai)(Br + i Bi) with three real products: X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi);
-        // Re = X - Y, Im = Z - X - Y
-        float16v gx, gy, gz;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            gx[r] = 0.f;
-            gy[r] = 0.f;
-            gz[r] = 0.f;
-        }
-        {
-            const float* Are = smem;
-            const float* Aim = smem + P;
-            const float* Bre = smem + 2 * P;
-            const float* Bim = smem + 3 * P;
-            (void)Are; (void)Aim; (void)Bre; (void)Bim;
-            const uint32_t ra = uint32_t(r0 + i), cb = uint32_t(c0 + i);
-            const uint32_t lds0 = uint32_t(uintptr_t(smem));
-            const uint32_t row_bytes = LD * 4;
-            // M_A[ra][k] = S_A[ra ^ k][k], M_B[k][cb] = S_B[k ^ cb][k].  Hand-scheduled: the operands
-            // of step s2+1 are read (re and im planes with one ds_read2st64) while the three MFMAs of
-            // step s2 run; byte address = (row * 65 + k) * 4 with a 24-bit multiply-add.
-            float2v av[2], bv[2];
-            uint32_t k4 = lds0 + 4u * uint32_t(h), kk = uint32_t(h);
-            auto issue = [&](float2v& a, float2v& b) {
-                uint32_t aa, ab;
-                // the running k (and 4k + base) are advanced inside the asm so that the 32 unrolled
-                // values are not precomputed outside the item loop (and spilled)
-                asm volatile("v_xor_b32 %0, %4, %2\n\tv_xor_b32 %1, %5, %2\n\t"
-                             "v_mad_u32_u24 %0, %0, %6, %3\n\tv_mad_u32_u24 %1, %1, %6, %3\n\t"
-                             "v_add_u32 %2, 2, %2\n\tv_add_u32 %3, 8, %3"
-                             : "=&v"(aa), "=&v"(ab), "+v"(kk), "+v"(k4) : "v"(ra), "v"(cb), "s"(row_bytes));
-                asm volatile("ds_read2st64_b32 %0, %1 offset1:65" : "=v"(a) : "v"(aa));
-                asm volatile("ds_read2st64_b32 %0, %1 offset0:130 offset1:195" : "=v"(b) : "v"(ab));
-            };
-            issue(av[0], bv[0]);
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                float2v& a = av[s2 & 1];
-                float2v& b = bv[s2 & 1];
-                asm volatile("" : "+v"(a), "+v"(b));   // the reads above have landed: values are live from here
-                if (s2 < 31) issue(av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, gz, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();  // every wave is done reading A and B
-
-        // ---- 4. C back to LDS, skewed: S_C[r ^ c][r] = C[r][c] (reusing the A planes).  Indexing the
-        // diagonal x = r ^ c by r (not c) keeps the 32 lanes of a store on 32 banks; the transform of a
-        // row shifted by x is the wanted one times (-1)^|x&z|, a sign the result table carries. ----
-        {
-            const int c = c0 + i;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                smem[(rr ^ c) * LD + rr] = gx[r] - gy[r];
-                smem[P + (rr ^ c) * LD + rr] = gz[r] - gx[r] - gy[r];
-            }
-        }
-        __syncthreads();
-        // inverse transform in place: V[x][z] = 2^-6 sum_c (-1)^|c & z| S_C[x][c]
-        // two threads per row (adjacent lanes): thread hb folds the halves with sign (-1)^hb, a 32-point
-        // transform then gives the outputs z = j + 32 hb
-        {
-            const int hb = tid & 1;
-            float* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
-            const float sg = hb ? -1.0f / 64.0f : 1.0f / 64.0f;
-            float v[32];
-#pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = row[c] * (1.0f / 64.0f) + row[c + 32] * sg;
-            wht<32>(v);
-#pragma unroll
-            for (int z = 0; z < 32; ++z) row[z + 32 * hb] = v[z];   // same wave as the partner's reads: ordered
-        }
-        __syncthreads();
-        // component of blade S(x,z): Re(V i^-k) = +re, +im, -re, -im for k = 0..3; rows written in order
-        {
-            float* orow = p.out + item * p.out_stride + tid;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t eo = entry(om, u);
-                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
-                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
-                if (p.out_full && !p.beta) {
-                    orow[256 * u] = val;
-                } else if (!(eo & 2u)) {
-                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
-                }
-            }
-        }
-        __syncthreads();  // the planes are free for the next item
     }
 }
 
@@ -322,7 +130,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     // sigma of the tile's rows / columns and the sign of the second k half: wave-uniform
     const uint32_t rho_mask = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;
     const uint32_t gam_mask = (p.has_alpha && (wave & 1)) ? 0x80000000u : 0u;
-    const float eps2 = p.has_alpha ? -1.f : 1.f;
 
     for (; item < p.batch; item += gridDim.x) {
 #pragma unroll
@@ -364,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
         // ---- 3. the product: X = p r, Y = q' s', Z = (p+q')(r+s'), k_5 = 0 first ----
         const int i = lane & 31, h = lane >> 5;
         const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
-        float16v gx, gy, gz, bank_re, bank_im;
+        float16v gx, gy, gz, bank_re;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             gx[r] = 0.f;
@@ -372,6 +179,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
             gz[r] = 0.f;
         }
         {
+            // p and q sit in one row, columns k and k ^ 2^LAMBIT (one ds_read2_b32; which of the pair is p
+            // is a compile-time property of the step).  The loop is left to the compiler's scheduler:
+            // a hand-scheduled, software-pipelined form measured 3 % slower.
             const float* A = smem;
             const float* B = smem + P;
             const uint32_t ra = uint32_t(r0 + i), cb = uint32_t(c0 + i);
@@ -380,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 const uint32_t k = uint32_t(2 * s2 + h);
                 const uint32_t ia = (ra ^ k) * LD + k, ib = (cb ^ k) * LD + k;
                 const bool hi = LAMBIT >= 0 && ((2 * s2) & LAM);          // k has the lambda bit: partner below
-                float pa = A[ia], pb = B[ib];
+                const float pa = A[ia], pb = B[ib];
                 float qa = LAMBIT < 0 ? pa : (hi ? A[ia - LAM] : A[ia + LAM]);
                 float qb = LAMBIT < 0 ? pb : (hi ? B[ib - LAM] : B[ib + LAM]);
                 qa = __uint_as_float(__float_as_uint(qa) ^ rho_mask);
@@ -388,15 +198,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 gx = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, pb, gx, 0, 0, 0);
                 gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
                 gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
-                if (s2 == 15) {
+                if (s2 == 15) {   // real part of the k_5 = 0 half; the accumulators keep running
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        bank_re[r] = gz[r] - gx[r] - gy[r];
-                        bank_im[r] = gx[r] - gy[r];
-                        gx[r] = 0.f;
-                        gy[r] = 0.f;
-                        gz[r] = 0.f;
-                    }
+                    for (int r = 0; r < 16; ++r) bank_re[r] = gz[r] - gx[r] - gy[r];
                 }
             }
         }
@@ -408,8 +212,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                smem[(rr ^ c) * LD + rr] = bank_re[r] + eps2 * (gz[r] - gx[r] - gy[r]);
-                smem[P + (rr ^ c) * LD + rr] = bank_im[r] + (gx[r] - gy[r]);
+                const float re_all = gz[r] - gx[r] - gy[r];            // both halves added
+                smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;   // first - second
+                smem[P + (rr ^ c) * LD + rr] = gx[r] - gy[r];
             }
         }
         __syncthreads();
@@ -540,7 +345,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
         }
         __syncthreads();
 
-        // complex D x D x D product, three real ones (see k_gp_spinor12)
+        // complex D x D x D product, three real ones: X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y
         acc_t gx, gy, gz;
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {

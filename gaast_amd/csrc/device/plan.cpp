@@ -376,7 +376,7 @@ struct Lowering {
                 packed.resize(map.size() / 2);
                 std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
             };
-            if (m == 6 && !(plan.flags & GAAST_FLAG_NO_MFMA)) {
+            if (m == 6) {
                 // one real plane per operand (k_gp_spinor12s): indices in the basis of spinor_basis.hpp
                 uint32_t alpha = 0, lam = 0;
                 for (uint32_t blade = 0; blade < (1u << (2 * m)); ++blade) {

@@ -208,7 +208,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
                 const size_t lds = (one_plane ? 2 : 4) * plane * sizeof(float);
                 KernS kern = one_plane ? (s.spinor_lam_bit == 5 ? &k_gp_spinor12s<5> : s.spinor_lam_bit == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>)
-                             : m == 6 ? &k_gp_spinor12 : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
+                             : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
                 const int threads = m == 6 ? 256 : 64;
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
