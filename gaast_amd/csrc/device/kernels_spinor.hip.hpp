@@ -262,14 +262,21 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 // Same algorithm for the smaller even dimensions: n = 8 (16 x 16 matrices, v_mfma_f32_16x16x4_f32)
 // and n = 10 (32 x 32, v_mfma_f32_32x32x2_f32); odd n runs as the subalgebra of n + 1.  One WAVE per
 // item (64-thread workgroups, persistent), so the phases need no cross-wave barrier, and the four
-// planes of an item are 5 KB / 17 KB of LDS.  Plane stride = a multiple of 64 words (re/im pairs by
-// ds_read2st64).  Table formats as in SpinorArgs with 65 -> D + 1 and 4160 -> the plane stride.
+// planes of an item are 4.3 KB / 17 KB of LDS.  Table formats as in SpinorArgs; positions and the
+// real -> imaginary distance follow the layouts below (the host mirrors them in plan.cpp).
 template <int M>
 __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int D = 1 << M, LD = D + 1, P = D * LD;
     constexpr int PS = (P + 63) / 64 * 64;
+    // M = 5: [operand][plane][x][z], rows of 33 words, plane stride a multiple of 64 words.
+    // M = 4: 16 rows only cover half the banks, so re and im of a row are interleaved,
+    //        [operand][x][plane][z] with 2 x 17 words per row: (plane, x) -> 32 distinct banks.
+    constexpr int RS = M == 4 ? 2 * LD : LD;             // row stride
+    constexpr int IMOFF = M == 4 ? LD : PS;              // real -> imaginary
+    constexpr int OPOFF = M == 4 ? D * RS : 2 * PS;      // left -> right operand
+    constexpr int TOTAL = 2 * OPOFF;
     constexpr int NE = D * D, EPL = NE / 64, RPL = 4 * D / 64;
     using acc_t = typename std::conditional<M == 4, float4v, float16v>::type;
     constexpr int NACC = M == 4 ? 4 : 16;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
 #pragma unroll
         for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
         if (!p.left_full || !p.right_full) {
-            for (int i = lane; i < 4 * PS; i += 64) smem[i] = 0.f;
+            for (int i = lane; i < TOTAL; i += 64) smem[i] = 0.f;
             __syncthreads();
         }
         {
@@ -320,12 +327,12 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
                 float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
                 const bool im = (e & 2u) != 0;
                 q[0] = im ? 0.f : a;
-                q[PS] = im ? a : 0.f;
+                q[IMOFF] = im ? a : 0.f;
             };
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
                 put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + 2 * PS, entry(rm, u), vb[u], p.canon_right);
+                put(smem + OPOFF, entry(rm, u), vb[u], p.canon_right);
             }
         }
         __syncthreads();
@@ -334,8 +341,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
         // row transforms: (operand, plane, x) = 4 D rows over 64 lanes
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
-            const int ridx = lane + 64 * j;
-            float* row = smem + (ridx >> M) * PS + (ridx & (D - 1)) * LD;
+            const int ridx = lane + 64 * j;          // (operand, plane, x)
+            float* row = smem + (ridx >> (M + 1)) * OPOFF + ((ridx >> M) & 1) * IMOFF + (ridx & (D - 1)) * RS;
             float v[D];
 #pragma unroll
             for (int z = 0; z < D; ++z) v[z] = row[z];
@@ -359,8 +366,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
 #pragma unroll
         for (int s2 = 0; s2 < D / KSTEP; ++s2) {
             const int k = KSTEP * s2 + kq;
-            const int idx = (i ^ k) * LD + k;     // M_A[i][k] = S_A[i^k][k], M_B[k][i] = S_B[k^i][k]
-            const float are = smem[idx], aim = smem[PS + idx], bre = smem[2 * PS + idx], bim = smem[3 * PS + idx];
+            const int idx = (i ^ k) * RS + k;     // M_A[i][k] = S_A[i^k][k], M_B[k][i] = S_B[k^i][k]
+            const float are = smem[idx], aim = smem[IMOFF + idx], bre = smem[OPOFF + idx], bim = smem[OPOFF + IMOFF + idx];
             if constexpr (M == 4) {
                 gx = __builtin_amdgcn_mfma_f32_16x16x4f32(are, bre, gx, 0, 0, 0);
                 gy = __builtin_amdgcn_mfma_f32_16x16x4f32(aim, bim, gy, 0, 0, 0);
@@ -376,8 +383,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
-            smem[(rr ^ i) * LD + rr] = gx[r] - gy[r];
-            smem[PS + (rr ^ i) * LD + rr] = gz[r] - gx[r] - gy[r];
+            smem[(rr ^ i) * RS + rr] = gx[r] - gy[r];
+            smem[IMOFF + (rr ^ i) * RS + rr] = gz[r] - gx[r] - gy[r];
         }
         __syncthreads();
         // inverse transform: (plane, x, half) = 4 D half-rows over 64 lanes
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
         for (int j = 0; j < RPL; ++j) {
             const int hidx = lane + 64 * j;
             const int hb = hidx & 1;
-            float* row = smem + (hidx >> (M + 1)) * PS + ((hidx >> 1) & (D - 1)) * LD;
+            float* row = smem + (hidx >> (M + 1)) * IMOFF + ((hidx >> 1) & (D - 1)) * RS;
             const float sc = 1.0f / float(D), sg = hb ? -sc : sc;
             float v[D / 2];
 #pragma unroll

@@ -344,6 +344,8 @@ struct Lowering {
             const int n = d.vec_space_dim;
             const int m = (n + 1) / 2;                 // 2^m x 2^m complex matrices
             const uint32_t D = 1u << m, LD = D + 1u, PS = (D * LD + 63u) / 64u * 64u;
+            // two-plane kernels (k_gp_spinor_wave): row stride and real -> imaginary distance of their layouts
+            const uint32_t RS = m == 4 ? 2u * LD : LD, IMOFF = m == 4 ? LD : PS;
             Step& s = emit(Step::PRODUCT_DENSE, res, "product_spinor_gemm[gp n=" + std::to_string(n) + "]");
             s.a = l;
             s.b = r;
@@ -366,8 +368,8 @@ struct Lowering {
                         pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
                         uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
                         if (role != 0) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
-                        const uint32_t pos = px * LD + pz;
-                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * PS + pos) << 2 | neg)
+                        const uint32_t pos = px * RS + pz;
+                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * IMOFF + pos) << 2 | neg)
                                                                    : uint16_t(pos << 2 | (pk & 1u) << 1 | neg);
                         ++count;
                     }

@@ -206,7 +206,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 const bool one_plane = s.use_spinor == 16;
                 const int m = one_plane ? 6 : s.use_spinor;
                 const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
-                const size_t lds = (one_plane ? 2 : 4) * plane * sizeof(float);
+                const size_t lds = (one_plane ? 2 * plane : m == 4 ? 2 * D * 2 * (D + 1) : 4 * plane) * sizeof(float);
                 KernS kern = one_plane ? (s.spinor_lam_bit == 5 ? &k_gp_spinor12s<5> : s.spinor_lam_bit == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>)
                              : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
                 const int threads = m == 6 ? 256 : 64;
