@@ -121,9 +121,9 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_EXACT_ORDER 0x4u    /* never use the dense re-ordered product kernel (bit-exact f64 sums) */
 #define GAAST_FLAG_NO_MFMA 0x8u        /* dense products stay on the vector-FMA kernel (A/B testing) */
 #define GAAST_FLAG_NO_JIT 0x10u        /* small programs run on the LDS interpreter kernel, not on hiprtc-specialised code */
-/* OPT-IN, not the reference's algorithm: dense f32 geometric products of a non-degenerate 12-dimensional
- * algebra go through the 64x64 complex matrix representation (16x fewer multiply-adds, all on the
- * matrix cores).  Equal to eval.rs:61-86 in exact arithmetic; in f32 the error is bounded norm-wise,
+/* OPT-IN, not the reference's algorithm: dense f32 geometric products of a non-degenerate algebra of
+ * dimension 7..12 go through the 2^m x 2^m complex matrix representation (at n = 12: 21x fewer
+ * multiply-adds, all on the matrix cores).  Equal to eval.rs:61-86 in exact arithmetic; in f32 the error is bounded norm-wise,
  * |err_S| <= 64 eps |A|_2 |B|_2, not per component.  Never selected without this flag. */
 #define GAAST_FLAG_SPINOR_GEMM 0x20u
 
