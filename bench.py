@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r8|r8s|cl41]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r12d|r8|r8s|cl41]
 
 A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
 multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
@@ -55,6 +55,12 @@ def workload_spec(name):
                     build=lambda a, b: a * b, entries=4 ** n, default_batch=65536, flags=ga.FLAG_SPINOR_GEMM,
                     flops_item=2 * 3 * 64 ** 3 + 2 * 384 * (256 + 64),
                     label="R^12 full MV x MV geometric product, f32, opt-in 64x64 complex matrix representation")
+    if name == "r12d":
+        n = 12
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=16384,
+                    label="R^12 full MV x MV geometric product, f64 (the reference's value type)")
     if name == "r8s":
         n = 8
         full = list(range(n + 1))
@@ -247,7 +253,7 @@ def main():
     # the same products through the opt-in matrix-representation kernel (not the reference's summation
     # order, so never `value`): reported beside the headline, with its distance from the default path
     alt = None
-    if args.workload in ("r12", "r8") and rank == 0 and not args.no_alt:
+    if args.workload in ("r12", "r8") and rank == 0 and world == 1 and not args.no_alt:
         spec_alt = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
         out_alt_t = torch.empty_like(out_t)
         out_alt = ga.DeviceMV.wrap_tensor(out_alt_t, n, ga.GradeSet(out_mask))
@@ -299,7 +305,8 @@ def main():
         if dense:
             roof = {"bound": "mfma", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
                     "traffic": None,
-                    "note": "dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); "
+                    "note": ("dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); " if dtype == ga.F32 else
+                             "dense product: fp64 vector FMA peak == fp64 MFMA peak (78.6 TFLOP/s); ") +
                             f"algorithmic HBM {ach_gb:.1f} GB/s = {ach_gb / PEAK_HBM_GBPS:.4f} of 8 TB/s"}
         else:
             roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
