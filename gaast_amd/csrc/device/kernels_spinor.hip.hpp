@@ -34,9 +34,9 @@ namespace gaast {
 //     transform), and the result rows are gathered in order so that the stores are coalesced.
 // ------------------------------------------------------------------------------------------
 struct SpinorArgs {
-    const float* left;
-    const float* right;
-    float* out;
+    const void* left;       // rows of float (f32 kernels) or double (k_gp_spinor12d); strides in elements
+    const void* right;
+    void* out;
     int64_t left_stride, right_stride, out_stride;
     // 4^m 16-bit entries each, indexed by ROW OFFSET (two per word); D = 2^m, LD = D + 1.
     //  operands: bit 0 = negate (folded unary signs, i^2, the right operand's shift), bit 1 = plane
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     float va[16], vb[16];
     const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
     auto fetch = [&](int64_t item) {
-        const float* lrow = p.left + item * p.left_stride + tid;
-        const float* rrow = p.right + item * p.right_stride + tid;
+        const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride + tid;
+        const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride + tid;
         if (rows_full) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -242,12 +242,225 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
         }
         __syncthreads();
         {
-            float* orow = p.out + item * p.out_stride + tid;
+            float* orow = static_cast<float*>(p.out) + item * p.out_stride + tid;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t eo = entry(om, u);
                 float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
                 val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[256 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The one-plane algorithm in f64 (the reference's value type), n = 11, 12: same tables, same phases,
+// planes of doubles (66.5 KB of LDS, two workgroups per CU), v_mfma_f64_16x16x4_f64.  A wave owns a
+// 32 x 32 tile of C as 2 x 2 MFMA tiles: per step of 4 k values, 4 ds_read2_b64 (p and q of two row
+// blocks of A and two column blocks of B) feed 12 MFMAs (X, Y, Z of the four tiles).  The next item's
+// rows are fetched after the accumulators have been written back (their registers are free then).
+// Norm-wise error bound as for f32 with eps = 2^-52.
+// ------------------------------------------------------------------------------------------
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int LAMBIT>
+__global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    constexpr int LD = 65, P = 64 * LD;
+    constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const double* left = static_cast<const double*>(p.left);
+    const double* right = static_cast<const double*>(p.right);
+    double* outp = static_cast<double*>(p.out);
+
+    uint32_t lm[8], rm[8], om[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
+        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
+        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    auto flip = [](double v, uint32_t sign_bit31) {     // sign flip through the high word
+        return __hiloint2double(__double2hiint(v) ^ int(sign_bit31), __double2loint(v));
+    };
+    double va[16], vb[16];
+    auto fetch = [&](int64_t item) {
+        const double* lrow = left + item * p.left_stride + tid;
+        const double* rrow = right + item * p.right_stride + tid;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            va[u] = e < p.left_len ? lrow[256 * u] : 0.0;
+            vb[u] = e < p.right_len ? rrow[256 * u] : 0.0;
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+    const uint32_t rho_mask = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;
+    const uint32_t gam_mask = (p.has_alpha && (wave & 1)) ? 0x80000000u : 0u;
+
+    for (; item < p.batch; item += gridDim.x) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        // ---- 1. graded rows -> W[x][z] ----
+        if (!p.left_full || !p.right_full) {
+            for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.0;
+            __syncthreads();
+        }
+        {
+            auto put = [&](double* plane, uint32_t e, double a, int canon) {
+                if (canon) a = 0.0 + a;
+                a = flip(a, e << 31);
+                *reinterpret_cast<double*>(reinterpret_cast<char*>(plane) + ((e & 0x7ffcu) << 1)) = a;
+            };
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + P, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. one transform per row, two threads per row ----
+        {
+            const int hb = tid & 1;
+            double* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
+            const double sg = hb ? -1.0 : 1.0;
+            double v[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = row[c] + row[c + 32] * sg;
+#pragma unroll
+            for (int hlf = 1; hlf < 32; hlf <<= 1) {
+#pragma unroll
+                for (int i2 = 0; i2 < 32; ++i2) {
+                    if ((i2 & hlf) == 0) {
+                        const double a = v[i2], b = v[i2 | hlf];
+                        v[i2] = a + b;
+                        v[i2 | hlf] = a - b;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c) row[c + 32 * hb] = v[c];
+        }
+        __syncthreads();
+
+        // ---- 3. the product on v_mfma_f64_16x16x4_f64: tiles (rb, cb), X = p r, Y = q' s', Z = (p+q')(r+s') ----
+        const int i = lane & 15, kq = lane >> 4;
+        const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
+        double4v gx[4], gy[4], gz[4], bank_re[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gx[t][r] = 0.0;
+                gy[t][r] = 0.0;
+                gz[t][r] = 0.0;
+            }
+        {
+            const double* A = smem;
+            const double* B = smem + P;
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const uint32_t k = uint32_t(4 * s4 + kq);
+                const bool hi = LAMBIT >= 0 && ((4 * s4) & LAM);
+                double pa[2], qa[2], pb[2], qb[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const uint32_t ra = uint32_t(r0 + 16 * blk + i), cb = uint32_t(c0 + 16 * blk + i);
+                    const uint32_t ia = (ra ^ k) * LD + k, ib = (cb ^ k) * LD + k;
+                    pa[blk] = A[ia];
+                    pb[blk] = B[ib];
+                    qa[blk] = LAMBIT < 0 ? pa[blk] : (hi ? A[ia - LAM] : A[ia + LAM]);
+                    qb[blk] = LAMBIT < 0 ? pb[blk] : (hi ? B[ib - LAM] : B[ib + LAM]);
+                    qa[blk] = flip(qa[blk], rho_mask);
+                    qb[blk] = flip(qb[blk], gam_mask);
+                }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cbk = 0; cbk < 2; ++cbk) {
+                        const int t = rb * 2 + cbk;
+                        gx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb], pb[cbk], gx[t], 0, 0, 0);
+                        gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cbk], gy[t], 0, 0, 0);
+                        gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cbk] + qb[cbk], gz[t], 0, 0, 0);
+                    }
+                if (s4 == 7) {   // real part of the k_5 = 0 half
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 4. C -> LDS, diagonals indexed by row; accumulator layout: col = lane & 15, row = (lane >> 4) + 4 r ----
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const int t = rb * 2 + cbk;
+                const int c = c0 + 16 * cbk + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + 16 * rb + kq + 4 * r;
+                    const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                    smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                    smem[P + (rr ^ c) * LD + rr] = gx[t][r] - gy[t][r];
+                }
+            }
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // the accumulators are dead: room for the rows
+        __syncthreads();
+        // ---- 5. four threads per row fold the plane that holds this quarter's components ----
+        {
+            constexpr int B1 = LAMBIT == 4 ? 4 : 5, B2 = LAMBIT == 4 ? 5 : 4;
+            const int x = tid >> 2, h1 = (tid >> 1) & 1, h2 = tid & 1;
+            const int xi = p.has_alpha ? (x >> 5) & 1 : 0;
+            const int f = LAMBIT >= 0 ? (xi ^ h1) : xi;
+            const double* q = smem + f * P + x * LD;
+            const double sc = 1.0 / 128.0;
+            const double s1 = h1 ? -sc : sc, s2f = h2 ? -1.0 : 1.0;
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double lo = q[j] * sc + q[j | (1 << B1)] * s1;
+                const double hi = q[j | (1 << B2)] * sc + q[j | (1 << B1) | (1 << B2)] * s1;
+                v[j] = lo + hi * s2f;
+            }
+#pragma unroll
+            for (int hlf = 1; hlf < 16; hlf <<= 1) {
+#pragma unroll
+                for (int i2 = 0; i2 < 16; ++i2) {
+                    if ((i2 & hlf) == 0) {
+                        const double a = v[i2], b = v[i2 | hlf];
+                        v[i2] = a + b;
+                        v[i2 | hlf] = a - b;
+                    }
+                }
+            }
+            double* o = smem + x * LD + (h1 << B1) + (h2 << B2);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = v[j];
+        }
+        __syncthreads();
+        {
+            double* orow = outp + item * p.out_stride + tid;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t eo = entry(om, u);
+                double val = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(smem) + ((eo & 0xfffcu) << 1));
+                val = flip(val, eo << 31);
                 if (p.out_full && !p.beta) {
                     orow[256 * u] = val;
                 } else if (!(eo & 2u)) {
@@ -293,8 +506,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
     float va[EPL], vb[EPL];
     const bool rows_full = p.left_len == NE && p.right_len == NE;
     auto fetch = [&](int64_t item) {
-        const float* lrow = p.left + item * p.left_stride + lane;
-        const float* rrow = p.right + item * p.right_stride + lane;
+        const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride + lane;
+        const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride + lane;
         if (rows_full) {
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
@@ -403,7 +616,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
         }
         __syncthreads();
         {
-            float* orow = p.out + item * p.out_stride + lane;
+            float* orow = static_cast<float*>(p.out) + item * p.out_stride + lane;
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
                 const uint32_t eo = entry(om, u);

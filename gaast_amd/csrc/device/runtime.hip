@@ -181,47 +181,49 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
     case Step::FUSED: return GAAST_OK;  // launched by run_fused (needs every bound buffer)
     case Step::PRODUCT_DENSE: {
         if (s.use_spinor) {
-            if constexpr (std::is_same<T, float>::value) {
-                SpinorArgs q;
-                q.left = static_cast<const float*>(a.ptr);
-                q.right = static_cast<const float*>(b.ptr);
-                q.out = static_cast<float*>(res.ptr);
-                q.left_stride = a.stride;
-                q.right_stride = b.stride;
-                q.out_stride = res.stride;
-                q.left_map = static_cast<const uint16_t*>(s.d_a);
-                q.right_map = static_cast<const uint16_t*>(s.d_b);
-                q.left_full = s.left_full;
-                q.right_full = s.right_full;
-                q.out_map = static_cast<const uint16_t*>(s.d_c);
-                q.out_full = s.out_full;
-                q.left_len = int(la.row_len);
-                q.right_len = int(lb.row_len);
-                q.canon_left = s.canon_a;
-                q.canon_right = s.canon_b;
-                q.beta = s.beta;
-                q.batch = batch;
-                using KernS = void (*)(SpinorArgs);
-                q.has_alpha = s.spinor_has_alpha;
-                const bool one_plane = s.use_spinor == 16;
-                const int m = one_plane ? 6 : s.use_spinor;
-                const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
-                const size_t lds = (one_plane ? 2 * plane : m == 4 ? 2 * D * 2 * (D + 1) : 4 * plane) * sizeof(float);
-                KernS kern = one_plane ? (s.spinor_lam_bit == 5 ? &k_gp_spinor12s<5> : s.spinor_lam_bit == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>)
-                             : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
-                const int threads = m == 6 ? 256 : 64;
-                if (lds > 64 * 1024)
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-                int per_cu = 0;
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
-                if (per_cu < 1) per_cu = 1;
-                int64_t blocks = int64_t(g_num_cu) * per_cu;
-                if (blocks > batch) blocks = batch;
-                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, q);
-                break;
-            }
-            return set_err(GAAST_ERR_INVALID_PROGRAM, "matrix-representation product is f32 only");
+            constexpr bool is_f64 = std::is_same<T, double>::value;
+            SpinorArgs q;
+            q.left = a.ptr;
+            q.right = b.ptr;
+            q.out = res.ptr;
+            q.left_stride = a.stride;
+            q.right_stride = b.stride;
+            q.out_stride = res.stride;
+            q.left_map = static_cast<const uint16_t*>(s.d_a);
+            q.right_map = static_cast<const uint16_t*>(s.d_b);
+            q.left_full = s.left_full;
+            q.right_full = s.right_full;
+            q.out_map = static_cast<const uint16_t*>(s.d_c);
+            q.out_full = s.out_full;
+            q.left_len = int(la.row_len);
+            q.right_len = int(lb.row_len);
+            q.canon_left = s.canon_a;
+            q.canon_right = s.canon_b;
+            q.beta = s.beta;
+            q.batch = batch;
+            q.has_alpha = s.spinor_has_alpha;
+            using KernS = void (*)(SpinorArgs);
+            const bool one_plane = s.use_spinor == 16;
+            if (is_f64 && !one_plane)
+                return set_err(GAAST_ERR_INVALID_PROGRAM, "f64 matrix-representation product exists for n = 11, 12 only");
+            const int m = one_plane ? 6 : s.use_spinor;
+            const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
+            const size_t lds = (one_plane ? 2 * plane : m == 4 ? 2 * D * 2 * (D + 1) : 4 * plane) * sizeof(T);
+            const int lb5 = s.spinor_lam_bit;
+            KernS kern = is_f64 ? (lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>)
+                         : one_plane ? (lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>)
+                         : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
+            const int threads = m == 6 ? 256 : 64;
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
+            if (per_cu < 1) per_cu = 1;
+            int64_t blocks = int64_t(g_num_cu) * per_cu;
+            if (blocks > batch) blocks = batch;
+            hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, q);
+            break;
         }
         DenseArgs<T> p;
         p.left = static_cast<const T*>(a.ptr);

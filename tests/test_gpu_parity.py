@@ -325,6 +325,46 @@ def test_spinor_gemm_smaller_dimensions_basis_blades_exact(n):
         assert np.array_equal(got[i], want), (i,)
 
 
+@pytest.mark.parametrize("n,midx", [(12, 0), (12, 1), (12, 3), (12, 4), (12, 5), (12, 6), (11, 0)])
+def test_spinor_gemm_f64(n, midx):
+    """the same path in f64 (the reference's value type): bound 64 * 2^-52 * |A| |B|, every index-basis case"""
+    metric = SPINOR_METRICS[midx][:n]
+    batch = 5
+    rng = np.random.default_rng(50 + midx)
+    rows = {0: rows_of(n, full_grades(n), batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    for i in range(batch):
+        A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
+        want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
+        bound = 64 * 2.0 ** -52 * np.linalg.norm(rows[0][i]) * np.linalg.norm(rows[1][i])
+        err = np.abs(got[i] - want).max()
+        assert err <= bound, (i, err, bound)
+
+
+def test_spinor_gemm_f64_basis_blades_exact():
+    n, N = 12, 4096
+    metric = SPINOR_METRICS[1]
+    rng = np.random.default_rng(60)
+    batch = 400
+    a_idx, b_idx = rng.integers(0, N, batch), rng.integers(0, N, batch)
+    ra, rb = np.zeros((batch, N)), np.zeros((batch, N))
+    ra[np.arange(batch), a_idx] = 1.0
+    rb[np.arange(batch), b_idx] = 1.0
+    got, _, spec = hip_eval_batch(_gp(n), metric, {0: ra, 1: rb}, batch, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches())
+    from helpers import blades_in_row_order
+    blades = blades_in_row_order(n, full_grades(n))
+    pos_of = np.zeros(N, dtype=np.int64)
+    pos_of[blades] = np.arange(N)
+    alg = ga.MetricAlgebra(metric)
+    for i in range(batch):
+        res, coeff = alg.ortho_basis_blades_gp(int(blades[a_idx[i]]), int(blades[b_idx[i]]))
+        want = np.zeros(N)
+        want[pos_of[res]] = coeff
+        assert np.array_equal(got[i], want), (i,)
+
+
 def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand():
     """rotor-like even operand (shared by all items), reversed on the fly, odd result only."""
     n, batch = 12, 3
