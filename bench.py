@@ -260,7 +260,7 @@ def main():
     # the same products through the opt-in matrix-representation kernel (not the reference's summation
     # order, so never `value`): reported beside the headline, with its distance from the default path
     alt = None
-    if args.workload in ("r12", "r8") and rank == 0 and world == 1 and not args.no_alt:
+    if args.workload in ("r12", "r12d", "r8") and rank == 0 and world == 1 and not args.no_alt:
         spec_alt = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
         out_alt_t = torch.empty_like(out_t)
         out_alt = ga.DeviceMV.wrap_tensor(out_alt_t, n, ga.GradeSet(out_mask))
@@ -278,9 +278,9 @@ def main():
         diff = (out_alt_t[sl].double() - out_t[sl].double()).abs().max().item()
         scale = (in_t[0][sl].double().norm(dim=1) * in_t[1][sl].double().norm(dim=1)).max().item()
         alt = {"kernel": [l for l in spec_alt.launches() if "product" in l][-1], "value": batch / (alt_ms * 1e-3),
-               "unit": "products/s", "kernel_ms": alt_ms, "algorithmic_GBps": batch * 3 * (1 << n) * 4 / (alt_ms * 1e-3) * 1e-9,
+               "unit": "products/s", "kernel_ms": alt_ms, "algorithmic_GBps": batch * 3 * (1 << n) * (4 if dtype == ga.F32 else 8) / (alt_ms * 1e-3) * 1e-9,
                "mfma_TFLOPs": batch * (3 * 2 * (1 << (n // 2)) ** 3) / (alt_ms * 1e-3) * 1e-12,
-               "max_abs_diff_vs_default_path": diff, "diff_over_eps_normA_normB": diff / (2.0 ** -23 * scale),
+               "max_abs_diff_vs_default_path": diff, "diff_over_eps_normA_normB": diff / ((2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52) * scale),
                "note": f"opt-in GAAST_FLAG_SPINOR_GEMM: {1 << (n // 2)}x{1 << (n // 2)} complex matrix representation, 3 real MFMA products per item; "
                        "norm-wise error bound, not the reference's summation order"}
         del out_alt_t, out_alt, spec_alt

@@ -369,9 +369,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
         {
             const double* A = smem;
             const double* B = smem + P;
+            uint32_t kk = uint32_t(kq);
+            asm volatile("" : "+v"(kk));   // addresses are computed per step, not hoisted out of the item loop
 #pragma unroll
             for (int s4 = 0; s4 < 16; ++s4) {
-                const uint32_t k = uint32_t(4 * s4 + kq);
+                const uint32_t k = kk;
+                kk += 4u;
                 const bool hi = LAMBIT >= 0 && ((4 * s4) & LAM);
                 double pa[2], qa[2], pb[2], qb[2];
 #pragma unroll
