@@ -365,27 +365,46 @@ def test_spinor_gemm_f64_basis_blades_exact():
         assert np.array_equal(got[i], want), (i,)
 
 
-def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand():
-    """rotor-like even operand (shared by all items), reversed on the fly, odd result only."""
-    n, batch = 12, 3
-    rng = np.random.default_rng(23)
+@pytest.mark.parametrize("n,dtype", [(12, ga.F32), (12, ga.F64), (11, ga.F64), (10, ga.F32), (8, ga.F32), (7, ga.F32)])
+def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand(n, dtype):
+    """rotor-like even operand (shared by all items), reversed on the fly, odd result only: partial tables,
+    zero-filled planes, folded unary signs, a batch-1 operand -- on every kernel of the path."""
+    batch, N = 3, 1 << n
+    npdt, eps = (np.float32, 2.0 ** -23) if dtype == ga.F32 else (np.float64, 2.0 ** -52)
+    rng = np.random.default_rng(23 + n)
     even = [k for k in range(n + 1) if k % 2 == 0]
     odd = [k for k in range(n + 1) if k % 2 == 1]
     build = lambda B: (B.input(0, even, n).rev() * B.input(1, full_grades(n), n)).gselect(odd)
-    rows = {0: rows_of(n, even, 1, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
-    spec = build(HipBackend()).specialize(n, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    rows = {0: rows_of(n, even, 1, rng, npdt), 1: rows_of(n, full_grades(n), batch, rng, npdt)}
+    spec = build(HipBackend()).specialize(n, dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
     out = spec.eval_batch([rows[0], rows[1]], batch)
     got = out.download_rows()
     assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
     A = row_to_bits(n, even, rows[0][0].astype(np.float64))
-    for m in range(4096):
+    for m in range(N):
         k = bin(m).count("1")
         if (k * (k - 1) // 2) % 2:
             A[m] = -A[m]
     for i in range(batch):
         full = gp_bits(n, [1.0] * n, A, row_to_bits(n, full_grades(n), rows[1][i].astype(np.float64)))
         want = bits_to_row(n, odd, full)
-        bound = 64 * 2.0 ** -23 * np.linalg.norm(A) * np.linalg.norm(rows[1][i].astype(np.float64))
+        bound = 64 * eps * np.linalg.norm(A) * np.linalg.norm(rows[1][i].astype(np.float64))
+        assert np.abs(got[i].astype(np.float64) - want).max() <= bound
+
+
+def test_spinor_gemm_accumulates_into_a_shared_result_buffer():
+    """(a*b + c*d): the second product adds into the buffer the first one wrote (beta = 1 in the kernel)."""
+    n, batch = 8, 9
+    rng = np.random.default_rng(77)
+    fg = full_grades(n)
+    build = lambda B: B.input(0, fg, n) * B.input(1, fg, n) + B.input(2, fg, n) * B.input(3, fg, n)
+    rows = {s: rows_of(n, fg, batch, rng, np.float32) for s in range(4)}
+    got, _, spec = hip_eval_batch(build, n, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert sum("product_spinor_gemm" in l for l in spec.launches()) == 2, spec.launches()
+    for i in range(batch):
+        bits = [row_to_bits(n, fg, rows[s][i].astype(np.float64)) for s in range(4)]
+        want = bits_to_row(n, fg, gp_bits(n, [1.0] * n, bits[0], bits[1]) + gp_bits(n, [1.0] * n, bits[2], bits[3]))
+        bound = 64 * 2.0 ** -23 * (np.linalg.norm(bits[0]) * np.linalg.norm(bits[1]) + np.linalg.norm(bits[2]) * np.linalg.norm(bits[3]))
         assert np.abs(got[i].astype(np.float64) - want).max() <= bound
 
 
