@@ -1,0 +1,130 @@
+// Host-side logic under AddressSanitizer + UBSan (CPU build only; no GPU, no HIP): programs are built
+// through the C host API of include/gaast_expr.h, lowered with gaast::build_plan (the launch plan and
+// every table the kernels index), serialized and deserialized.  Any out-of-bounds table write or
+// undefined shift in the bitmask arithmetic aborts the run.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gaast_expr.h"
+#include "plan.hpp"
+
+static int failures = 0;
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__);  \
+            ++failures;                                                 \
+        }                                                               \
+    } while (0)
+
+static uint64_t full_mask(int n) { return (uint64_t(2) << n) - 1; }
+
+// every handle the driver creates is released at the end, so that LeakSanitizer reports the library only
+static std::vector<gaast_expr_t> handles;
+static gaast_expr_t H(gaast_expr_t e) {
+    handles.push_back(e);
+    return e;
+}
+#define gaast_expr_input(...) H(gaast_expr_input(__VA_ARGS__))
+#define gaast_expr_product(...) H(gaast_expr_product(__VA_ARGS__))
+#define gaast_expr_add(...) H(gaast_expr_add(__VA_ARGS__))
+#define gaast_expr_sub(...) H(gaast_expr_sub(__VA_ARGS__))
+#define gaast_expr_g(...) H(gaast_expr_g(__VA_ARGS__))
+#define gaast_expr_rev(...) H(gaast_expr_rev(__VA_ARGS__))
+#define gaast_expr_ginvol(...) H(gaast_expr_ginvol(__VA_ARGS__))
+#define gaast_expr_neg(...) H(gaast_expr_neg(__VA_ARGS__))
+#define gaast_expr_vinv(...) H(gaast_expr_vinv(__VA_ARGS__))
+#define gaast_expr_gselect_mask(...) H(gaast_expr_gselect_mask(__VA_ARGS__))
+
+static void lower(gaast_expr_t e, int n, const double* metric, int dtype, uint32_t flags, const char* what,
+                  const char* expect_step) {
+    gaast_spec_t spec = gaast_expr_specialize(e, n, metric, 1 << 16);
+    CHECK(spec != nullptr);
+    if (!spec) return;
+    gaast_program_desc desc;
+    CHECK(gaast_spec_program_desc(spec, dtype, flags, &desc) == 0);
+    gaast::Plan plan;
+    gaast::build_plan(desc, plan);
+    bool found = expect_step == nullptr;
+    for (const gaast::Step& s : plan.steps)
+        if (expect_step && s.name.find(expect_step) != std::string::npos) found = true;
+    if (!found) std::printf("%s: no step named *%s*\n", what, expect_step);
+    CHECK(found);
+    // wire format round trip, then lower the decoded image too
+    const size_t need = gaast_program_serialize(&desc, nullptr, 0);
+    std::vector<unsigned char> buf(need);
+    CHECK(gaast_program_serialize(&desc, buf.data(), buf.size()) == need);
+    gaast_program_image_t img = gaast_program_deserialize(buf.data(), buf.size());
+    CHECK(img != nullptr);
+    if (img) {
+        gaast::Plan plan2;
+        gaast::build_plan(*gaast_program_image_desc(img), plan2);
+        CHECK(plan2.steps.size() == plan.steps.size());
+        gaast_program_image_free(img);
+    }
+    for (size_t cut = 0; cut < need; cut += need / 7 + 1)   // truncated images are rejected, not read past
+        CHECK(gaast_program_deserialize(buf.data(), cut) == nullptr);
+    gaast_spec_free(spec);
+    std::printf("ok  %s (%zu steps)\n", what, plan.steps.size());
+}
+
+int main() {
+    const double euclid[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const double cga[5] = {1, 1, 1, 1, -1};
+    const double mixed12[12] = {1, 1, -1, 1, -1, -1, -1, -1, 1, 1, -1, 1};      // lambda on bit 4
+    const double alt12[12] = {1, -1, 1, -1, 1, -1, 1, -1, 1, -1, 1, -1};        // lambda = 0
+    {   // BASELINE config 1: (a + b*c).g(2) in R^3
+        gaast_expr_t a = gaast_expr_input(0, full_mask(3), 3), b = gaast_expr_input(1, full_mask(3), 3),
+                     c = gaast_expr_input(2, full_mask(3), 3);
+        gaast_expr_t e = gaast_expr_g(gaast_expr_add(a, gaast_expr_product(b, c, GAAST_PROD_GEOMETRIC)), 2);
+        lower(e, 3, euclid, GAAST_F64, 0, "cfg1", "ast_");
+        lower(e, 3, euclid, GAAST_F64, GAAST_FLAG_NO_FUSION, "cfg1 unfused", "product_csr");
+    }
+    {   // config 5: R X ~R in R^{4,1}
+        gaast_expr_t r = gaast_expr_input(0, 0x15, 5), x = gaast_expr_input(1, 0x2, 5);
+        gaast_expr_t e = gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC);
+        lower(e, 5, cga, GAAST_F64, 0, "cfg5 sandwich", "ast_");
+        lower(e, 5, cga, GAAST_F32, GAAST_FLAG_NO_JIT, "cfg5 sandwich f32", "ast_");
+    }
+    for (int n : {6, 7, 8, 9, 10, 11, 12, 13}) {   // dense products: vector / matrix-core / matrix-representation tables
+        gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
+        gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
+        char what[64];
+        std::snprintf(what, sizeof what, "dense gp n=%d f32", n);
+        lower(e, n, euclid, GAAST_F32, 0, what, "product_dense");
+        if (n <= 12) {
+            std::snprintf(what, sizeof what, "dense gp n=%d f64", n);
+            lower(e, n, euclid, GAAST_F64, 0, what, "product_dense");
+        }
+        if (n >= 7 && n <= 12) {
+            std::snprintf(what, sizeof what, "matrix representation n=%d f32", n);
+            lower(e, n, euclid, GAAST_F32, GAAST_FLAG_SPINOR_GEMM, what, "product_spinor_gemm");
+        }
+    }
+    {
+        gaast_expr_t a = gaast_expr_input(0, full_mask(12), 12), b = gaast_expr_input(1, full_mask(12), 12);
+        gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
+        lower(e, 12, mixed12, GAAST_F32, GAAST_FLAG_SPINOR_GEMM, "matrix representation n=12 lambda on bit 4", "lam=4");
+        lower(e, 12, alt12, GAAST_F64, GAAST_FLAG_SPINOR_GEMM, "matrix representation n=12 f64 lambda = 0", "lam=-1");
+        // partial operands and result: even * full -> odd grades
+        gaast_expr_t ev = gaast_expr_input(0, 0x1555, 12);
+        gaast_expr_t e2 = gaast_expr_gselect_mask(gaast_expr_product(gaast_expr_rev(ev), b, GAAST_PROD_GEOMETRIC), 0x0aaa);
+        lower(e2, 12, euclid, GAAST_F32, GAAST_FLAG_SPINOR_GEMM, "matrix representation n=12 partial", "product_spinor_gemm");
+        lower(e2, 12, euclid, GAAST_F32, 0, "dense n=12 partial", "product_dense");
+    }
+    {   // the other products and unary arms on R^4
+        gaast_expr_t a = gaast_expr_input(0, full_mask(4), 4), b = gaast_expr_input(1, full_mask(4), 4);
+        for (int kind : {GAAST_PROD_OUTER, GAAST_PROD_INNER, GAAST_PROD_LCONTRACT, GAAST_PROD_RCONTRACT})
+            lower(gaast_expr_product(a, b, kind), 4, euclid, GAAST_F64, 0, "r4 product kinds", nullptr);
+        lower(gaast_expr_sub(gaast_expr_ginvol(a), gaast_expr_neg(gaast_expr_rev(b))), 4, euclid, GAAST_F64, 0, "unary chain", nullptr);
+        lower(gaast_expr_vinv(gaast_expr_input(2, 0x2, 4)), 4, euclid, GAAST_F64, 0, "vinv", nullptr);
+    }
+    for (gaast_expr_t h : handles) gaast_expr_release(h);
+    if (failures) {
+        std::printf("%d failures\n", failures);
+        return 1;
+    }
+    std::printf("ALL OK\n");
+    return 0;
+}
