@@ -1,0 +1,96 @@
+//! Raw bindings to `libgaast_hip.so` (C ABI of `include/gaast_hip.h`).  NOT COMPILED in this repository.
+#![allow(dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const GAAST_OK: c_int = 0;
+pub const GAAST_F64: c_int = 0;
+pub const GAAST_F32: c_int = 1;
+pub const GAAST_PROD_EXPLICIT: i32 = -1;
+
+// gaast_opcode, in the order of AstNode's variants (base_types.rs:8-30) + ScalarUnaryOp (:84-88)
+pub const OP_INPUT: i32 = 0;
+pub const OP_ADD: i32 = 1;
+pub const OP_PRODUCT: i32 = 2;
+pub const OP_NEG: i32 = 3;
+pub const OP_EXP: i32 = 4;
+pub const OP_LOG: i32 = 5;
+pub const OP_PROJ: i32 = 6;
+pub const OP_REVERSE: i32 = 7;
+pub const OP_GINVOL: i32 = 8;
+pub const OP_SINV: i32 = 9;
+pub const OP_SSQRT: i32 = 10;
+
+pub const FLAG_EXACT_ORDER: u32 = 0x4; // bit-exact f64 sums even for dense products
+pub const FLAG_SPINOR_GEMM: u32 = 0x20; // opt-in matrix-representation products (norm-wise error bound)
+
+#[repr(C)]
+pub struct GaastCompMul {
+    pub left_grade: u32,
+    pub left_index: u32,
+    pub right_grade: u32,
+    pub right_index: u32,
+    pub result_grade: u32,
+    pub result_index: u32,
+    pub coeff: f64,
+}
+
+#[repr(C)]
+pub struct GaastNodeDesc {
+    pub opcode: i32,
+    pub child0: i32,
+    pub child1: i32,
+    pub minimal_grade_mask: u64,
+    pub vec_space_dim: i32,
+    pub input_slot: i32,
+    pub product_kind: i32,
+    pub n_comp_muls: u64,
+    pub comp_muls: *const GaastCompMul,
+}
+
+#[repr(C)]
+pub struct GaastInputDesc {
+    pub grade_mask: u64,
+    pub storage_dim: i32,
+    pub is_const: i32,
+    pub const_row: *const f64,
+}
+
+#[repr(C)]
+pub struct GaastProgramDesc {
+    pub vec_space_dim: i32,
+    pub metric_diag: *const f64,
+    pub dtype: i32,
+    pub n_nodes: i32,
+    pub nodes: *const GaastNodeDesc,
+    pub root: i32,
+    pub n_inputs: i32,
+    pub inputs: *const GaastInputDesc,
+    pub flags: u32,
+}
+
+pub type Program = *mut c_void;
+pub type Mv = *mut c_void;
+
+#[link(name = "gaast_hip")]
+extern "C" {
+    pub fn gaast_hip_init(device_ids: *const c_int, n_dev: c_int) -> c_int;
+    pub fn gaast_hip_shutdown() -> c_int;
+    pub fn gaast_hip_synchronize() -> c_int;
+    pub fn gaast_hip_last_error() -> *const c_char;
+    pub fn gaast_hip_program_create(desc: *const GaastProgramDesc, out: *mut Program) -> c_int;
+    pub fn gaast_hip_program_destroy(p: Program) -> c_int;
+    pub fn gaast_hip_program_output_info(p: Program, mask: *mut u64, row_len: *mut i64) -> c_int;
+    pub fn gaast_hip_mv_alloc(dim: c_int, mask: u64, batch: i64, dtype: c_int, out: *mut Mv) -> c_int;
+    pub fn gaast_hip_mv_free(m: Mv) -> c_int;
+    pub fn gaast_hip_mv_upload(m: Mv, grade: c_int, host: *const c_void, count: i64) -> c_int;
+    pub fn gaast_hip_mv_download(m: Mv, grade: c_int, host: *mut c_void, count: i64) -> c_int;
+    pub fn gaast_hip_eval(p: Program, inputs: *const Mv, n_inputs: c_int, batch: i64, out: Mv) -> c_int;
+}
+
+/// Turns a non-zero status into the panic the reference would have raised.
+pub fn check(status: c_int, what: &str) {
+    if status != GAAST_OK {
+        let msg = unsafe { std::ffi::CStr::from_ptr(gaast_hip_last_error()) };
+        panic!("gaast_hip: {} failed with status {}: {}", what, status, msg.to_string_lossy());
+    }
+}
