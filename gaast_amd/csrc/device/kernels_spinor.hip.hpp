@@ -39,11 +39,11 @@ struct SpinorArgs {
     void* out;
     int64_t left_stride, right_stride, out_stride;
     // 4^m 16-bit entries each, indexed by ROW OFFSET (two per word); D = 2^m, LD = D + 1.
-    //  operands: bit 0 = negate (folded unary signs, i^2, the right operand's shift), bit 1 = plane
-    //            (two-plane kernels: 0 real, 1 imaginary = parity of k), bits [14:2] = x*LD+z, i.e.
-    //            entry & 0x7ffc is the byte offset inside a plane; offsets that hold nothing point at a
-    //            padding word (x*LD+z = D)
-    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = plane*stride + x*LD+z
+    //  operands: bit 0 = negate (folded unary signs, (-1)^u of the phase, the right operand's shift),
+    //            bits [14:2] = x'*LD + z' (indices in the basis of spinor_basis.hpp), i.e. entry & 0x7ffc
+    //            is the byte offset inside a plane of floats; offsets that hold nothing point at a
+    //            padding word (x'*LD + z' = D)
+    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = x'*LD + z' 
     const uint16_t* left_map;
     const uint16_t* right_map;
     const uint16_t* out_map;
@@ -475,28 +475,29 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
     }
 }
 
-// Same algorithm for the smaller even dimensions: n = 8 (16 x 16 matrices, v_mfma_f32_16x16x4_f32)
-// and n = 10 (32 x 32, v_mfma_f32_32x32x2_f32); odd n runs as the subalgebra of n + 1.  One WAVE per
-// item (64-thread workgroups, persistent), so the phases need no cross-wave barrier, and the four
-// planes of an item are 4.3 KB / 17 KB of LDS.  Table formats as in SpinorArgs; positions and the
-// real -> imaginary distance follow the layouts below (the host mirrors them in plan.cpp).
-template <int M>
-__global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
+// The same one-plane algorithm for the smaller even dimensions: n = 8 (16 x 16 matrices,
+// v_mfma_f32_16x16x4_f32) and n = 10 (32 x 32, v_mfma_f32_32x32x2_f32); odd n runs as the subalgebra of
+// n + 1.  One WAVE per item (64-thread workgroups, persistent), so the phases need no cross-wave
+// barrier, and the two planes of an item are 2.2 KB / 8.4 KB of LDS.  LAMBIT is M-1, M-2 or -1
+// (spinor_basis.hpp); alpha', when present, is the top bit M-1, so the sign of q / s is a lane
+// constant (top bit of the lane's row / column) and the k loop banks the real part after its first
+// half.  (A variant with separate real and imaginary planes, two transforms per row, measured 7 %
+// slower at n = 8 and is not kept.)
+template <int M, int LAMBIT>
+__global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int D = 1 << M, LD = D + 1, P = D * LD;
-    constexpr int PS = (P + 63) / 64 * 64;
-    // M = 5: [operand][plane][x][z], rows of 33 words, plane stride a multiple of 64 words.
-    // M = 4: 16 rows only cover half the banks, so re and im of a row are interleaved,
-    //        [operand][x][plane][z] with 2 x 17 words per row: (plane, x) -> 32 distinct banks.
-    constexpr int RS = M == 4 ? 2 * LD : LD;             // row stride
-    constexpr int IMOFF = M == 4 ? LD : PS;              // real -> imaginary
-    constexpr int OPOFF = M == 4 ? D * RS : 2 * PS;      // left -> right operand
-    constexpr int TOTAL = 2 * OPOFF;
-    constexpr int NE = D * D, EPL = NE / 64, RPL = 4 * D / 64;
+    constexpr int NE = D * D, EPL = NE / 64;
+    constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
+    constexpr int FWD_PASSES = 4 * D / 64, INV_PASSES = 4 * D / 64;
     using acc_t = typename std::conditional<M == 4, float4v, float16v>::type;
     constexpr int NACC = M == 4 ? 4 : 16;
+    constexpr int KSTEP = 64 / D, NSTEPS = D / KSTEP;
     const int lane = threadIdx.x;
+    const float* left = static_cast<const float*>(p.left);
+    const float* right = static_cast<const float*>(p.right);
+    float* outp = static_cast<float*>(p.out);
 
     uint32_t lm[EPL / 2], rm[EPL / 2], om[EPL / 2];
 #pragma unroll
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
     float va[EPL], vb[EPL];
     const bool rows_full = p.left_len == NE && p.right_len == NE;
     auto fetch = [&](int64_t item) {
-        const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride + lane;
-        const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride + lane;
+        const float* lrow = left + item * p.left_stride + lane;
+        const float* rrow = right + item * p.right_stride + lane;
         if (rows_full) {
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
@@ -528,98 +529,123 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave(SpinorArgs p) {
     };
     int64_t item = blockIdx.x;
     if (item < p.batch) fetch(item);
+    const int i = lane & (D - 1);
+    const int kq = lane >> M;
+    const uint32_t sig_mask = (p.has_alpha && (i >> (M - 1))) ? 0x80000000u : 0u;   // sigma of row i / column i
 
     for (; item < p.batch; item += gridDim.x) {
 #pragma unroll
         for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
         if (!p.left_full || !p.right_full) {
-            for (int i = lane; i < TOTAL; i += 64) smem[i] = 0.f;
+            for (int j = lane; j < 2 * P; j += 64) smem[j] = 0.f;
             __syncthreads();
         }
         {
-            auto put = [&](float* planes, uint32_t e, float a, int canon) {
+            auto put = [&](float* plane, uint32_t e, float a, int canon) {
                 if (canon) a = 0.f + a;
                 a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
-                float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + (e & 0x7ffcu));
-                const bool im = (e & 2u) != 0;
-                q[0] = im ? 0.f : a;
-                q[IMOFF] = im ? a : 0.f;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (e & 0x7ffcu)) = a;
             };
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
                 put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + OPOFF, entry(rm, u), vb[u], p.canon_right);
+                put(smem + P, entry(rm, u), vb[u], p.canon_right);
             }
         }
         __syncthreads();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
 
-        // row transforms: (operand, plane, x) = 4 D rows over 64 lanes
+        // one transform per row, two threads per row: (operand, x, half) = 4 D half-rows over 64 lanes
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const int ridx = lane + 64 * j;          // (operand, plane, x)
-            float* row = smem + (ridx >> (M + 1)) * OPOFF + ((ridx >> M) & 1) * IMOFF + (ridx & (D - 1)) * RS;
-            float v[D];
+        for (int j = 0; j < FWD_PASSES; ++j) {
+            const int hidx = lane + 64 * j;
+            const int hb = hidx & 1;
+            float* row = smem + (hidx >> (M + 1)) * P + ((hidx >> 1) & (D - 1)) * LD;
+            const float sg = hb ? -1.f : 1.f;
+            float v[D / 2];
 #pragma unroll
-            for (int z = 0; z < D; ++z) v[z] = row[z];
-            wht<D>(v);
+            for (int c = 0; c < D / 2; ++c) v[c] = row[c] + row[c + D / 2] * sg;
+            wht<D / 2>(v);
 #pragma unroll
-            for (int c = 0; c < D; ++c) row[c] = v[c];
+            for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
         }
         __syncthreads();
 
-        // complex D x D x D product, three real ones: X = Ar Br, Y = Ai Bi, Z = (Ar+Ai)(Br+Bi); Re = X - Y, Im = Z - X - Y
-        acc_t gx, gy, gz;
+        acc_t gx, gy, gz, bank_re;
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             gx[r] = 0.f;
             gy[r] = 0.f;
             gz[r] = 0.f;
         }
-        const int i = lane & (D - 1);
-        const int kq = lane >> M;                 // M = 4: 0..3 (k = 4 s + kq);  M = 5: 0..1 (k = 2 s + kq)
-        constexpr int KSTEP = 64 / D;             // k values per MFMA
 #pragma unroll
-        for (int s2 = 0; s2 < D / KSTEP; ++s2) {
+        for (int s2 = 0; s2 < NSTEPS; ++s2) {
             const int k = KSTEP * s2 + kq;
-            const int idx = (i ^ k) * RS + k;     // M_A[i][k] = S_A[i^k][k], M_B[k][i] = S_B[k^i][k]
-            const float are = smem[idx], aim = smem[IMOFF + idx], bre = smem[OPOFF + idx], bim = smem[OPOFF + IMOFF + idx];
+            const int idx = (i ^ k) * LD + k;
+            const bool hi = LAMBIT >= 0 && ((KSTEP * s2) & LAM);
+            const float pa = smem[idx], pb = smem[P + idx];
+            float qa = LAMBIT < 0 ? pa : (hi ? smem[idx - LAM] : smem[idx + LAM]);
+            float qb = LAMBIT < 0 ? pb : (hi ? smem[P + idx - LAM] : smem[P + idx + LAM]);
+            qa = __uint_as_float(__float_as_uint(qa) ^ sig_mask);
+            qb = __uint_as_float(__float_as_uint(qb) ^ sig_mask);
             if constexpr (M == 4) {
-                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(are, bre, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_16x16x4f32(aim, bim, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_16x16x4f32(are + aim, bre + bim, gz, 0, 0, 0);
+                gx = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, gz, 0, 0, 0);
             } else {
-                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, gz, 0, 0, 0);
+                gx = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, pb, gx, 0, 0, 0);
+                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
+                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+            }
+            if (s2 == NSTEPS / 2 - 1) {   // k_top = 0 half done
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) bank_re[r] = gz[r] - gx[r] - gy[r];
             }
         }
         __syncthreads();
-        // C back, diagonals indexed by row: S_C[r ^ c][r] = C[r][c]
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
-            smem[(rr ^ i) * RS + rr] = gx[r] - gy[r];
-            smem[IMOFF + (rr ^ i) * RS + rr] = gz[r] - gx[r] - gy[r];
+            const float re_all = gz[r] - gx[r] - gy[r];
+            smem[(rr ^ i) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;
+            smem[P + (rr ^ i) * LD + rr] = gx[r] - gy[r];
         }
         __syncthreads();
-        // inverse transform: (plane, x, half) = 4 D half-rows over 64 lanes
+        // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
+        {
+            constexpr int B1 = LAMBIT == M - 2 ? M - 2 : M - 1, B2 = LAMBIT == M - 2 ? M - 1 : M - 2;
+            constexpr int Q = D / 4;
+            float v[INV_PASSES][Q];
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const int hidx = lane + 64 * j;
-            const int hb = hidx & 1;
-            float* row = smem + (hidx >> (M + 1)) * IMOFF + ((hidx >> 1) & (D - 1)) * RS;
-            const float sc = 1.0f / float(D), sg = hb ? -sc : sc;
-            float v[D / 2];
+            for (int j = 0; j < INV_PASSES; ++j) {
+                const int tix = lane + 64 * j;
+                const int x = tix >> 2, h1 = (tix >> 1) & 1, h2 = tix & 1;
+                const int xi = p.has_alpha ? (x >> (M - 1)) & 1 : 0;
+                const int f = LAMBIT >= 0 ? (xi ^ h1) : xi;
+                const float* q = smem + f * P + x * LD;
+                const float sc = 0.5f / float(D);
+                const float s1 = h1 ? -sc : sc, s2f = h2 ? -1.f : 1.f;
 #pragma unroll
-            for (int c = 0; c < D / 2; ++c) v[c] = row[c] * sc + row[c + D / 2] * sg;
-            wht<D / 2>(v);
+                for (int c = 0; c < Q; ++c) {
+                    const float lo = q[c] * sc + q[c | (1 << B1)] * s1;
+                    const float up = q[c | (1 << B2)] * sc + q[c | (1 << B1) | (1 << B2)] * s1;
+                    v[j][c] = lo + up * s2f;
+                }
+                wht<Q>(v[j]);
+            }
+            __syncthreads();   // every pass has read its planes before any result lands in plane 0
 #pragma unroll
-            for (int z = 0; z < D / 2; ++z) row[z + (D / 2) * hb] = v[z];
+            for (int j = 0; j < INV_PASSES; ++j) {
+                const int tix = lane + 64 * j;
+                const int x = tix >> 2, h1 = (tix >> 1) & 1, h2 = tix & 1;
+                float* o = smem + x * LD + (h1 << B1) + (h2 << B2);
+#pragma unroll
+                for (int c = 0; c < Q; ++c) o[c] = v[j][c];
+            }
         }
         __syncthreads();
         {
-            float* orow = static_cast<float*>(p.out) + item * p.out_stride + lane;
+            float* orow = outp + item * p.out_stride + lane;
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
                 const uint32_t eo = entry(om, u);

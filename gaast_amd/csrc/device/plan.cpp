@@ -16,6 +16,7 @@
 #include "spinor_basis.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -344,9 +345,7 @@ struct Lowering {
             if (beta0) removed[size_t(fr->second)] = 1;
             const int n = d.vec_space_dim;
             const int m = (n + 1) / 2;                 // 2^m x 2^m complex matrices
-            const uint32_t D = 1u << m, LD = D + 1u, PS = (D * LD + 63u) / 64u * 64u;
-            // two-plane kernels (k_gp_spinor_wave): row stride and real -> imaginary distance of their layouts
-            const uint32_t RS = m == 4 ? 2u * LD : LD, IMOFF = m == 4 ? LD : PS;
+            const uint32_t D = 1u << m, LD = D + 1u;
             Step& s = emit(Step::PRODUCT_DENSE, res, "product_spinor_gemm[gp n=" + std::to_string(n) + "]");
             s.a = l;
             s.b = r;
@@ -355,32 +354,9 @@ struct Lowering {
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
             s.use_spinor = m;
-            // D*D 16-bit entries indexed by row offset, two per word (formats: SpinorArgs, kernels.hip.hpp)
-            auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
-                // role 0 = left, 1 = right, 2 = result; the transformed rows of the right operand and of the
-                // result are stored shifted by x, which is the sign (-1)^|x&z| here
-                const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(D << 2);   // padding word of row 0
-                std::vector<uint16_t> map(size_t(D) * D, nothing);
-                size_t count = 0;
-                for (int k = 0; k <= n; ++k) {
-                    if (!((want >> k) & 1ULL)) continue;
-                    for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
-                        uint32_t px, pz, pk;
-                        pauli_string(bt.blade_of[size_t(k)][i], &px, &pz, &pk);
-                        uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ (pk >> 1);
-                        if (role != 0) neg ^= uint32_t(__builtin_popcount(px & pz) & 1);
-                        const uint32_t pos = px * RS + pz;
-                        map[size_t(lay.offset(k) + i)] = role == 2 ? uint16_t(((pk & 1u) * IMOFF + pos) << 2 | neg)
-                                                                   : uint16_t(pos << 2 | (pk & 1u) << 1 | neg);
-                        ++count;
-                    }
-                }
-                *full = count == size_t(D) * D;
-                packed.resize(map.size() / 2);
-                std::memcpy(packed.data(), map.data(), map.size() * sizeof(uint16_t));
-            };
-            if (m == 6) {
-                // one real plane per operand (k_gp_spinor12s): indices in the basis of spinor_basis.hpp
+            {
+                // D*D 16-bit table entries indexed by row offset, two per word (format: SpinorArgs);
+                // one real plane per operand: indices in the basis of spinor_basis.hpp
                 uint32_t alpha = 0, lam = 0;
                 for (uint32_t blade = 0; blade < (1u << (2 * m)); ++blade) {
                     uint32_t px, pz, pk;
@@ -391,10 +367,9 @@ struct Lowering {
                 const SpinorBasis sb = choose_spinor_basis(m, alpha, lam);
                 s.spinor_lam_bit = sb.lam_bit;
                 s.spinor_has_alpha = sb.has_alpha ? 1 : 0;
-                s.use_spinor = 16;   // the one-plane kernel
                 auto build1 = [&](const Layout& lay, uint64_t want, uint64_t flip, int role, std::vector<uint32_t>& packed, int* full) {
-                    // operands: bit 0 = negate, bits [14:2] = x'*65 + z'; result: bit 0 = negate, bit 1 = nothing
-                    // to store, bits [15:2] = x'*65 + z'
+                    // operands: bit 0 = negate, bits [14:2] = x'*LD + z'; result: bit 0 = negate, bit 1 = nothing
+                    // to store, bits [15:2] = x'*LD + z'
                     const uint16_t nothing = role == 2 ? uint16_t(2u) : uint16_t(D << 2);
                     std::vector<uint16_t> map(size_t(D) * D, nothing);
                     size_t count = 0;
@@ -420,15 +395,10 @@ struct Lowering {
                 build1(ll, lmin & ll.mask, flip_l, 0, s.u32_a, &s.left_full);
                 build1(lrr, rmin & lrr.mask, flip_r, 1, s.u32_b, &s.right_full);
                 build1(lr, omin, 0, 2, s.u32_c, &s.out_full);
-                s.name = "product_spinor_gemm[gp n=" + std::to_string(n) + " one-plane lam=" + std::to_string(sb.lam_bit) + "]";
+                s.name = "product_spinor_gemm[gp n=" + std::to_string(n) + " lam=" + std::to_string(sb.lam_bit) + "]";
                 touch(res);
                 return;
             }
-            build_map(ll, lmin & ll.mask, flip_l, 0, s.u32_a, &s.left_full);
-            build_map(lrr, rmin & lrr.mask, flip_r, 1, s.u32_b, &s.right_full);
-            build_map(lr, omin, 0, 2, s.u32_c, &s.out_full);
-            touch(res);
-            return;
         }
         if (dense_eligible(nd, res, l, r)) {
             if ((omin & lr.mask) != omin) {

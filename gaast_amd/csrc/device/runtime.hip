@@ -203,16 +203,17 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             q.batch = batch;
             q.has_alpha = s.spinor_has_alpha;
             using KernS = void (*)(SpinorArgs);
-            const bool one_plane = s.use_spinor == 16;
-            if (is_f64 && !one_plane)
+            const int m = s.use_spinor;
+            if (is_f64 && m != 6)
                 return set_err(GAAST_ERR_INVALID_PROGRAM, "f64 matrix-representation product exists for n = 11, 12 only");
-            const int m = one_plane ? 6 : s.use_spinor;
             const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
-            const size_t lds = (one_plane ? 2 * plane : m == 4 ? 2 * D * 2 * (D + 1) : 4 * plane) * sizeof(T);
+            const size_t lds = (m == 6 ? 2 * plane : 2 * D * (D + 1)) * sizeof(T);
             const int lb5 = s.spinor_lam_bit;
-            KernS kern = is_f64 ? (lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>)
-                         : one_plane ? (lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>)
-                         : m == 5 ? &k_gp_spinor_wave<5> : &k_gp_spinor_wave<4>;
+            KernS kern = nullptr;
+            if (is_f64) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
+            else if (m == 6) kern = lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>;
+            else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
+            else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;
             const int threads = m == 6 ? 256 : 64;
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -284,8 +284,13 @@ def test_spinor_gemm_basis_blades_exact(metric):
         assert np.array_equal(got[i], want), (i, a, b)
 
 
-@pytest.mark.parametrize("n,neg", [(7, ()), (8, ()), (8, (0, 3, 6)), (9, (1, 8)), (10, ()), (10, (2, 3, 9)), (11, (0, 10))])
-def test_spinor_gemm_smaller_dimensions(n, neg):
+@pytest.mark.parametrize("n,neg,variant", [
+    (7, (), None), (8, (), None), (8, (0, 3, 6), None), (9, (1, 8), None), (10, (), None), (10, (2, 3, 9), None), (11, (0, 10), None),
+    # every case of the index basis (spinor_basis.hpp) on the 16 x 16 and the 32 x 32 kernels
+    (8, (2, 3, 6, 7), "lam=3"), (8, (2, 3, 4), "lam=2"), (8, (0, 1, 2, 3, 4, 6), "lam=3"), (8, (0, 3, 4, 7), "lam=-1"), (8, (1, 3, 5, 7), "lam=-1"),
+    (10, (2, 3, 6, 7, 8, 9), "lam=4"), (10, (0, 1, 3, 4, 8), "lam=3"), (10, (1, 2, 5, 7, 9), "lam=-1"), (10, (2, 4, 5, 8, 9), "lam=4"),
+    (10, (1, 3, 5, 7, 9), "lam=-1")])
+def test_spinor_gemm_smaller_dimensions(n, neg, variant):
     """n = 8 and 10 on the wave-per-item kernels, odd n as the subalgebra of n + 1."""
     metric = [-1.0 if i in neg else 1.0 for i in range(n)]
     batch = 67
@@ -293,6 +298,8 @@ def test_spinor_gemm_smaller_dimensions(n, neg):
     rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
     got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
     assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    if variant:
+        assert any(variant in l for l in spec.launches()), spec.launches()
     for i in range(0, batch, 11):
         A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
         want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
