@@ -203,11 +203,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(workload_spec(args.workload))
+    # GAAST_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through gloo on host copies).  Never set by the driver; numbers
+    # from such a run are not measurements.
+    rehearsal = world > 1 and os.environ.get("GAAST_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     ga.init_device(local_rank)
     stream = torch.cuda.current_stream()
     ga._lib.check(ga.lib().gaast_hip_set_stream(C.c_void_p(stream.cuda_stream)))
@@ -259,7 +268,7 @@ def main():
     wall = time.perf_counter() - t0
     if world > 1:
         from gaast_amd.sharding import max_over_ranks
-        wall = max_over_ranks(wall, device=dev)
+        wall = max_over_ranks(wall, device=None if rehearsal else dev)
     step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     kernel_ms = sum(step_ms) / len(step_ms)
 
@@ -294,10 +303,11 @@ def main():
     # final gather of the result shards to rank 0 over RCCL (xGMI), outside the timed region
     gather_ms = None
     if world > 1 and not args.no_gather:
-        glist = [torch.empty_like(out_t) for _ in range(world)] if rank == 0 else None
+        send = out_t.cpu() if rehearsal else out_t
+        glist = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
         fence()
         g0 = time.perf_counter()
-        dist.gather(out_t, glist, dst=0)
+        dist.gather(send, glist, dst=0)
         fence()
         gather_ms = (time.perf_counter() - g0) * 1e3
         del glist
@@ -337,6 +347,7 @@ def main():
             "value": value, "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": wl["dtname"], "data": "synthetic",
+            **({"rehearsal": "ranks share GPUs, gloo collectives: control-flow check only, not a measurement"} if rehearsal else {}),
             "config": {"workload": wl["label"], "dim": n, "batch_per_gpu": batch, "global_batch": batch * world,
                        "launches_per_eval": launches, "specialize_s": t_spec},
             "roofline": roof,
