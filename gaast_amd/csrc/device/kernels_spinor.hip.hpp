@@ -43,14 +43,14 @@ struct SpinorArgs {
     //            bits [14:2] = x'*LD + z' (indices in the basis of spinor_basis.hpp), i.e. entry & 0x7ffc
     //            is the byte offset inside a plane of floats; offsets that hold nothing point at a
     //            padding word (x'*LD + z' = D)
-    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = x'*LD + z' 
+    //  result:   bit 0 = negate, bit 1 = nothing to store, bits [15:2] = x'*LD + z'
     const uint16_t* left_map;
     const uint16_t* right_map;
     const uint16_t* out_map;
     int left_len, right_len;
     int out_full;
     int left_full, right_full;
-    int has_alpha;           // one-plane kernel: alpha' = e_5 (see spinor_basis.hpp)
+    int has_alpha;           // alpha' = the top index bit (else 0), see spinor_basis.hpp
     int canon_left, canon_right;
     int beta;
     int64_t batch;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void wht(float (&v)[N]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// n = 12 with ONE real plane per operand (derivation, numpy prototype and the exhaustive check over
+// n = 11, 12, f32.  ONE real plane per operand (derivation, numpy prototype and the exhaustive check over
 // signatures: tools/proto/spinor_single_plane.py; index bookkeeping: spinor_basis.hpp).
 //
 // The phase of a blade is i^k, k = 2u + f, and f is linear in the index pair.  In the basis chosen by
