@@ -82,8 +82,8 @@ __device__ __forceinline__ void wht(float (&v)[N]) {
 // -- one transform per row instead of two, half the staging writes, half the LDS (33 KB), and
 //     E(p,q') E(r,s') = (p s' + q' r)/2 + i (p r - q' s')/2
 // is again three real products X = p r, Y = q' s', Z = (p+q')(r+s').  sigma_A sigma_B leaves a factor
-// (-1)^(k_5) on the real part only: the k loop runs k_5 = 0 first, banks Z-X-Y and X-Y, and subtracts
-// the real part of the second half.  Component S(x,z) = (-1)^u Re(i^-f V[x][z]) reads the real or the
+// (-1)^(k_5) on the real part only: the k loop runs k_5 = 0 first and banks Z-X-Y of that half (real part =
+// first half - second half = 2 bank - total; imaginary part = total of X-Y).  Component S(x,z) = (-1)^u Re(i^-f V[x][z]) reads the real or the
 // imaginary plane of C per (row, z_LAMBIT): four threads per row fold ONE plane over bits LAMBIT and
 // the other of {4,5} and transform the remaining 16 points.
 // LAMBIT = -1: lambda = 0 (q = p, every phase of a row is the same).
