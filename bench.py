@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r12d|r12ds|r8|r8d|r8s|r8x|cl41]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r12d|r12ds|r12x|r8|r8d|r8s|r8x|cl41]
 
 A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
 multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
@@ -68,6 +68,12 @@ def workload_spec(name):
                     build=lambda a, b: a * b, entries=4 ** n, default_batch=16384, flags=ga.FLAG_SPINOR_GEMM,
                     flops_item=2 * 3 * 64 ** 3 + 2 * 384 * (128 + 64),
                     label="R^12 full MV x MV geometric product, f64, opt-in 64x64 complex matrix representation")
+    if name == "r12x":
+        n = 12
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=512, flags=ga.FLAG_EXACT_ORDER,
+                    label="R^12 full MV x MV geometric product, f64, reference summation order (bit-exact kernel)")
     if name == "r8d":
         n = 8
         full = list(range(n + 1))
