@@ -118,4 +118,73 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_product_ell: the exact product for lists whose rows (result components) all have the same
+// number of entries and whose coefficients are +-1 -- every dense product of a non-degenerate
+// algebra.  Same terms in the same (reference) order with the same three roundings per term as
+// k_product_csr, but the list is stored [term][row] with the sign in bit 31: a wave's 64 rows read 64
+// consecutive words per term instead of 64 separate streams, no coefficient array is read, and one
+// pass over the list serves ITEMS batch items (their operand rows stay in LDS).
+//     entry = left offset [15:0] | right offset [30:16] | negate [31]
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct EllArgs {
+    const T* left;
+    const T* right;
+    T* out;
+    int64_t left_stride, right_stride, out_stride;
+    int left_len, right_len;
+    int canon_left, canon_right;
+    const uint32_t* row_out;   // output offset of each row
+    const uint32_t* entries;   // [width][n_rows]
+    int n_rows, width;
+    int beta;
+    int64_t batch;
+};
+
+template <typename T, int ITEMS>
+__global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* ls = reinterpret_cast<T*>(smem_raw);
+    T* rs = ls + int64_t(ITEMS) * p.left_len;
+    const int64_t item0 = int64_t(blockIdx.x) * ITEMS;
+    const int nitems = int(p.batch - item0 < ITEMS ? p.batch - item0 : ITEMS);
+    const int tid = threadIdx.x;
+    const T zero = T(0);
+    // operand rows of ITEMS items; rows beyond the batch are zero (their results are not stored)
+    for (int i = tid; i < ITEMS * p.left_len; i += 256) {
+        const int it = i / p.left_len, c = i - it * p.left_len;
+        T v = it < nitems ? p.left[(item0 + it) * p.left_stride + c] : zero;
+        ls[i] = p.canon_left ? zero + v : v;
+    }
+    for (int i = tid; i < ITEMS * p.right_len; i += 256) {
+        const int it = i / p.right_len, c = i - it * p.right_len;
+        T v = it < nitems ? p.right[(item0 + it) * p.right_stride + c] : zero;
+        rs[i] = p.canon_right ? zero + v : v;
+    }
+    __syncthreads();
+
+    for (int row = tid; row < p.n_rows; row += 256) {
+        const uint32_t oo = p.row_out[row];
+        T acc[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) acc[it] = (p.beta && it < nitems) ? p.out[(item0 + it) * p.out_stride + oo] : zero;
+        const uint32_t* ep = p.entries + row;
+#pragma unroll 4
+        for (int t = 0; t < p.width; ++t) {
+            const uint32_t e = ep[size_t(t) * p.n_rows];
+            const uint32_t lo = e & 0xffffu, ro = (e >> 16) & 0x7fffu;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];   // eval.rs:82, left * right
+                prod = (e >> 31) ? -prod : prod;                                   // ... * coeff, coeff = +-1
+                acc[it] = acc[it] + prod;                                          // ... +=
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+            if (it < nitems) p.out[(item0 + it) * p.out_stride + oo] = acc[it];
+    }
+}
+
 }  // namespace gaast

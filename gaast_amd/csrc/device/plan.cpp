@@ -814,6 +814,34 @@ bool try_fuse(Plan& plan) {
 
 }  // namespace
 
+// Rows of one length with +-1 coefficients (dense products of non-degenerate algebras) that were not fused
+// into a small-program launch: the same lists transposed to [term][row] with the sign in bit 31 --
+// consecutive threads (rows) then read consecutive words and no coefficient array is streamed
+// (k_product_ell).  Same order, same roundings: (l * r) * (-1.0) is -(l * r) exactly.
+static void uniform_csr_to_ell(Plan& plan) {
+    if (plan.flags & GAAST_FLAG_NO_FUSION) return;
+    for (Step& s : plan.steps) {
+        if (s.kind != Step::PRODUCT_CSR || s.u32_b.empty()) continue;
+        const size_t n_rows = s.u32_b.size();
+        const uint32_t width = s.u32_a[1] - s.u32_a[0];
+        bool uniform = width >= 16;
+        for (size_t i = 0; uniform && i < n_rows; ++i) uniform = s.u32_a[i + 1] - s.u32_a[i] == width;
+        for (size_t e = 0; uniform && e < s.coeff.size(); ++e) uniform = s.coeff[e] == 1.0 || s.coeff[e] == -1.0;
+        for (size_t e = 0; uniform && e < s.u32_c.size(); ++e) uniform = !(s.u32_c[e] & 0x80000000u);   // right offset < 2^15
+        if (!uniform) continue;
+        std::vector<uint32_t> ell(size_t(width) * n_rows);
+        for (size_t row = 0; row < n_rows; ++row)
+            for (uint32_t t = 0; t < width; ++t) {
+                const size_t e = size_t(s.u32_a[row]) + t;
+                ell[size_t(t) * n_rows + row] = s.u32_c[e] | (s.coeff[e] < 0.0 ? 0x80000000u : 0u);
+            }
+        s.u32_c.swap(ell);
+        s.coeff.clear();
+        s.ell_width = int(width);
+        s.name = "product_ell" + s.name.substr(s.name.find('['));
+    }
+}
+
 void build_plan(const gaast_program_desc& desc, Plan& plan) {
     if (desc.vec_space_dim < 0 || desc.vec_space_dim > GAAST_MAX_DIM) throw std::runtime_error("vec_space_dim out of range");
     if (desc.n_nodes <= 0 || desc.root < 0 || desc.root >= desc.n_nodes) throw std::runtime_error("bad node count / root");
@@ -869,7 +897,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
     for (size_t i = 0; i < plan.steps.size(); ++i)
         if (!lw.removed[i]) kept.push_back(std::move(plan.steps[i]));
     plan.steps = std::move(kept);
-    try_fuse(plan);
+    if (!try_fuse(plan)) uniform_csr_to_ell(plan);
 }
 
 }  // namespace gaast

@@ -142,6 +142,41 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                            static_cast<T*>(res.ptr), res.stride, s.sunary_off, s.sunary_op, batch);
         break;
     case Step::PRODUCT_CSR: {
+        if (s.ell_width > 0) {
+            EllArgs<T> q;
+            q.left = static_cast<const T*>(a.ptr);
+            q.right = static_cast<const T*>(b.ptr);
+            q.out = static_cast<T*>(res.ptr);
+            q.left_stride = a.stride;
+            q.right_stride = b.stride;
+            q.out_stride = res.stride;
+            q.left_len = int(la.row_len);
+            q.right_len = int(lb.row_len);
+            q.canon_left = s.canon_a;
+            q.canon_right = s.canon_b;
+            q.row_out = static_cast<const uint32_t*>(s.d_b);
+            q.entries = static_cast<const uint32_t*>(s.d_c);
+            q.n_rows = int(s.u32_b.size());
+            q.width = s.ell_width;
+            q.beta = s.beta;
+            q.batch = batch;
+            const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
+            if (per_item > g_max_lds)
+                return set_err(GAAST_ERR_INVALID_PROGRAM, "product operands do not fit in LDS (exact kernel)");
+            // items per pass over the list: as many as a 64 KiB share of LDS holds (at least one), at most 8
+            int items = int((64 * 1024) / per_item);
+            items = items >= 8 ? 8 : items >= 4 ? 4 : items >= 2 ? 2 : 1;
+            while (items > 1 && int64_t(items) > batch) items >>= 1;
+            using KernE = void (*)(EllArgs<T>);
+            KernE kern = items == 8 ? &k_product_ell<T, 8> : items == 4 ? &k_product_ell<T, 4> : items == 2 ? &k_product_ell<T, 2> : &k_product_ell<T, 1>;
+            const size_t lds = per_item * size_t(items);
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            const int64_t blocks = (batch + items - 1) / items;
+            hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(256), lds, g_stream, q);
+            break;
+        }
         CsrArgs<T> p;
         p.left = static_cast<const T*>(a.ptr);
         p.right = static_cast<const T*>(b.ptr);

@@ -225,6 +225,45 @@ def test_dense_n12_basis_blades_exact():
         assert np.array_equal(got[i], want)
 
 
+# ---- exact dense products on the transposed-list kernel (k_product_ell) ---------------------------
+@pytest.mark.parametrize("n,neg,batch", [(7, (), 21), (8, (), 19), (8, (1, 4, 6), 8), (9, (0,), 5)])
+def test_exact_order_dense_product_is_bit_exact(n, neg, batch):
+    """GAAST_FLAG_EXACT_ORDER, programs too big to fuse: rows of one length with +-1 coefficients run on
+    k_product_ell -- same terms, same order, same roundings as eval.rs:77-83, several items per pass."""
+    metric = [-1.0 if i in neg else 1.0 for i in range(n)]
+    rng = np.random.default_rng(90 + n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    want, omask = oracle_eval_batch(_gp(n), metric, rows, batch)
+    got, hmask, spec = hip_eval_batch(_gp(n), metric, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+    assert any("product_ell" in l for l in spec.launches()), spec.launches()
+    assert hmask == omask and np.array_equal(got, want)
+
+
+def test_exact_order_sum_of_dense_products_accumulates_bit_exact():
+    """a*b + c*d: the second product adds into the buffer the first one wrote (beta = 1), reference order"""
+    n, batch = 8, 11
+    fg = full_grades(n)
+    rng = np.random.default_rng(91)
+    build = lambda B: B.input(0, fg, n) * B.input(1, fg, n) + B.input(2, fg, n) * B.input(3, fg, n)
+    rows = {s: rows_of(n, fg, batch, rng) for s in range(4)}
+    want, _ = oracle_eval_batch(build, n, rows, batch)
+    got, _, spec = hip_eval_batch(build, n, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+    assert sum("product_ell" in l for l in spec.launches()) == 2, spec.launches()
+    assert np.array_equal(got, want)
+
+
+def test_exact_order_degenerate_metric_keeps_the_coefficient_list():
+    """a zero in the metric makes 0.0 coefficients (entries the reference still executes): k_product_csr"""
+    n, batch = 7, 6
+    metric = [1.0, 1.0, 0.0, 1.0, -1.0, 1.0, 1.0]
+    rng = np.random.default_rng(92)
+    rows = {0: rows_of(n, full_grades(n), batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    want, _ = oracle_eval_batch(_gp(n), metric, rows, batch)
+    got, _, spec = hip_eval_batch(_gp(n), metric, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+    assert any("product_csr" in l for l in spec.launches()), spec.launches()
+    assert np.array_equal(got, want)
+
+
 # ---- opt-in matrix-representation product (GAAST_FLAG_SPINOR_GEMM) ------------------------------
 # Not the reference's summation: equal in exact arithmetic, so the check is the norm-wise bound the
 # header states, |err_S| <= 64 eps |A|_2 |B|_2, against the float64 bitmask convolution.
