@@ -170,15 +170,33 @@ __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) acc[it] = (p.beta && it < nitems) ? p.out[(item0 + it) * p.out_stride + oo] : zero;
         const uint32_t* ep = p.entries + row;
-#pragma unroll 4
-        for (int t = 0; t < p.width; ++t) {
+        // 32 list words are loaded before they are used, to have that many loads in flight (the list comes
+        // from L2 / MALL: 64 MiB at n = 12); widths of dense products are multiples of 32 from n = 5 on
+        int t = 0;
+        for (; t + 32 <= p.width; t += 32) {
+            uint32_t ev[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) ev[j] = ep[size_t(t + j) * p.n_rows];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t e = ev[j];
+                const uint32_t lo = e & 0xffffu, ro = (e >> 16) & 0x7fffu;
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];   // eval.rs:82, left * right
+                    prod = (e >> 31) ? -prod : prod;                                   // ... * coeff, coeff = +-1
+                    acc[it] = acc[it] + prod;                                          // ... +=
+                }
+            }
+        }
+        for (; t < p.width; ++t) {
             const uint32_t e = ep[size_t(t) * p.n_rows];
             const uint32_t lo = e & 0xffffu, ro = (e >> 16) & 0x7fffu;
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];   // eval.rs:82, left * right
-                prod = (e >> 31) ? -prod : prod;                                   // ... * coeff, coeff = +-1
-                acc[it] = acc[it] + prod;                                          // ... +=
+                T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];
+                prod = (e >> 31) ? -prod : prod;
+                acc[it] = acc[it] + prod;
             }
         }
 #pragma unroll
