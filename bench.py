@@ -104,6 +104,20 @@ def workload_spec(name):
                     inputs=[[0, 2, 4], [1]], build=lambda r, x: r * x * r.rev(), entries=80 + 256,
                     default_batch=1 << 22,
                     label="R^{4,1} rotor sandwich R X ~R, f64 (BASELINE configs[4])")
+    import re
+    m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order)
+    if m:
+        n, dt, var = int(m.group(1)), m.group(2), m.group(3)
+        full = list(range(n + 1))
+        sz = 4 if dt == "f32" else 8
+        batch = max(64, min(1 << 22, (1 << 30) // ((1 << n) * sz)))          # 1 GiB per operand
+        if var == "x":
+            batch = max(64, batch >> 6)
+        flags = ga.FLAG_SPINOR_GEMM if var == "s" else ga.FLAG_EXACT_ORDER if var == "x" else 0
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F32 if dt == "f32" else ga.F64, dtname=dt, inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=batch, flags=flags,
+                    label=f"R^{n} full MV x MV geometric product, {dt}" +
+                          (", opt-in matrix representation" if var == "s" else ", reference summation order" if var == "x" else ""))
     raise SystemExit(f"unknown workload {name}")
 
 
