@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 // k_product_csr, but the list is stored [term][row] with the sign in bit 31: a wave's 64 rows read 64
 // consecutive words per term instead of 64 separate streams, no coefficient array is read, and one
 // pass over the list serves ITEMS batch items (their operand rows stay in LDS).
-//     entry = left offset [15:0] | right offset [30:16] | negate [31]
+//     entry = left offset [15:0] | right offset [30:16] | negate [31]   (element or byte offsets)
 // ------------------------------------------------------------------------------------------
 template <typename T>
 struct EllArgs {
@@ -142,7 +142,14 @@ struct EllArgs {
     int64_t batch;
 };
 
-template <typename T, int ITEMS>
+__device__ __forceinline__ float ell_flip(float v, uint32_t sign31) { return __uint_as_float(__float_as_uint(v) ^ sign31); }
+__device__ __forceinline__ double ell_flip(double v, uint32_t sign31) {
+    return __hiloint2double(__double2hiint(v) ^ int(sign31), __double2loint(v));
+}
+
+// BYTES: the two offsets of an entry are byte offsets (rows of at most 32 KiB), added to the LDS address of an
+// item's row as they are; otherwise element offsets.
+template <typename T, int ITEMS, bool BYTES>
 __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* ls = reinterpret_cast<T*>(smem_raw);
@@ -163,6 +170,9 @@ __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
         rs[i] = p.canon_right ? zero + v : v;
     }
     __syncthreads();
+    const char* lsb = reinterpret_cast<const char*>(ls);
+    const char* rsb = reinterpret_cast<const char*>(rs);
+    const int lbytes = p.left_len * int(sizeof(T)), rbytes = p.right_len * int(sizeof(T));
 
     for (int row = tid; row < p.n_rows; row += 256) {
         const uint32_t oo = p.row_out[row];
@@ -170,6 +180,18 @@ __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) acc[it] = (p.beta && it < nitems) ? p.out[(item0 + it) * p.out_stride + oo] : zero;
         const uint32_t* ep = p.entries + row;
+        auto term = [&](uint32_t e) {
+            const uint32_t sign = e & 0x80000000u;
+            const uint32_t lo = BYTES ? (e & 0x7fffu) : (e & 0xffffu) * uint32_t(sizeof(T));
+            const uint32_t ro = BYTES ? ((e >> 16) & 0x7fffu) : ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T));
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const T l = *reinterpret_cast<const T*>(lsb + it * lbytes + lo);
+                const T r = *reinterpret_cast<const T*>(rsb + it * rbytes + ro);
+                const T prod = ell_flip(l * r, sign);      // eval.rs:82: (left * right) * coeff, coeff = +-1
+                acc[it] = acc[it] + prod;                   // ... +=
+            }
+        };
         // 32 list words are loaded before they are used, to have that many loads in flight (the list comes
         // from L2 / MALL: 64 MiB at n = 12); widths of dense products are multiples of 32 from n = 5 on
         int t = 0;
@@ -178,27 +200,9 @@ __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) ev[j] = ep[size_t(t + j) * p.n_rows];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const uint32_t e = ev[j];
-                const uint32_t lo = e & 0xffffu, ro = (e >> 16) & 0x7fffu;
-#pragma unroll
-                for (int it = 0; it < ITEMS; ++it) {
-                    T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];   // eval.rs:82, left * right
-                    prod = (e >> 31) ? -prod : prod;                                   // ... * coeff, coeff = +-1
-                    acc[it] = acc[it] + prod;                                          // ... +=
-                }
-            }
+            for (int j = 0; j < 32; ++j) term(ev[j]);
         }
-        for (; t < p.width; ++t) {
-            const uint32_t e = ep[size_t(t) * p.n_rows];
-            const uint32_t lo = e & 0xffffu, ro = (e >> 16) & 0x7fffu;
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                T prod = ls[it * p.left_len + lo] * rs[it * p.right_len + ro];
-                prod = (e >> 31) ? -prod : prod;
-                acc[it] = acc[it] + prod;
-            }
-        }
+        for (; t < p.width; ++t) term(ep[size_t(t) * p.n_rows]);
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it)
             if (it < nitems) p.out[(item0 + it) * p.out_stride + oo] = acc[it];

@@ -829,12 +829,21 @@ static void uniform_csr_to_ell(Plan& plan) {
         for (size_t e = 0; uniform && e < s.coeff.size(); ++e) uniform = s.coeff[e] == 1.0 || s.coeff[e] == -1.0;
         for (size_t e = 0; uniform && e < s.u32_c.size(); ++e) uniform = !(s.u32_c[e] & 0x80000000u);   // right offset < 2^15
         if (!uniform) continue;
+        // offsets in BYTES when they fit 15 bits (rows of <= 32 KiB: n <= 12 in f64, n <= 13 in f32): the kernel
+        // then adds them to an LDS base without scaling
+        const uint32_t elem = plan.dtype == GAAST_F32 ? 4u : 8u;
+        bool bytes = true;
+        for (size_t e = 0; bytes && e < s.u32_c.size(); ++e)
+            bytes = (s.u32_c[e] & 0xffffu) * elem < 32768u && (s.u32_c[e] >> 16) * elem < 32768u;
         std::vector<uint32_t> ell(size_t(width) * n_rows);
         for (size_t row = 0; row < n_rows; ++row)
             for (uint32_t t = 0; t < width; ++t) {
                 const size_t e = size_t(s.u32_a[row]) + t;
-                ell[size_t(t) * n_rows + row] = s.u32_c[e] | (s.coeff[e] < 0.0 ? 0x80000000u : 0u);
+                const uint32_t lo = s.u32_c[e] & 0xffffu, ro = s.u32_c[e] >> 16;
+                const uint32_t word = bytes ? (lo * elem) | ((ro * elem) << 16) : s.u32_c[e];
+                ell[size_t(t) * n_rows + row] = word | (s.coeff[e] < 0.0 ? 0x80000000u : 0u);
             }
+        s.ell_bytes = bytes ? 1 : 0;
         s.u32_c.swap(ell);
         s.coeff.clear();
         s.ell_width = int(width);

@@ -46,6 +46,7 @@ struct Step {
     std::vector<double> coeff_host; // FUSED: the general coefficients, passed by value at launch
     std::vector<int32_t> i32_a;    // DENSE out_map
     int sunary_op = 0, sunary_off = 0;
+    int ell_bytes = 0;             // ... and the offsets of its entries are byte offsets
     int ell_width = 0;             // PRODUCT_CSR with rows of one length and +-1 coefficients: u32_c is [term][row], sign in bit 31
     int canon_a = 0, canon_b = 0;
     int beta = 1;

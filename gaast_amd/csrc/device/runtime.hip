@@ -168,7 +168,8 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             items = items >= 8 ? 8 : items >= 4 ? 4 : items >= 2 ? 2 : 1;
             while (items > 1 && int64_t(items) > batch) items >>= 1;
             using KernE = void (*)(EllArgs<T>);
-            KernE kern = items == 8 ? &k_product_ell<T, 8> : items == 4 ? &k_product_ell<T, 4> : items == 2 ? &k_product_ell<T, 2> : &k_product_ell<T, 1>;
+            KernE kern = s.ell_bytes ? (items == 8 ? &k_product_ell<T, 8, true> : items == 4 ? &k_product_ell<T, 4, true> : items == 2 ? &k_product_ell<T, 2, true> : &k_product_ell<T, 1, true>)
+                                     : (items == 8 ? &k_product_ell<T, 8, false> : items == 4 ? &k_product_ell<T, 4, false> : items == 2 ? &k_product_ell<T, 2, false> : &k_product_ell<T, 1, false>);
             const size_t lds = per_item * size_t(items);
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
