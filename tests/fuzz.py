@@ -62,6 +62,38 @@ def _reseed(rng, spec):
     return tuple(_reseed(rng, s) if isinstance(s, tuple) else s for s in spec)
 
 
+def random_big_program(seed):
+    """(n, metric, spec) with n = 7, 8 and dense leaves: too big to fuse, so the plan is a sequence of
+    launches (exact list kernels, copies, sign flips) even without GAAST_FLAG_NO_FUSION"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([7, 8]))
+    metric = [1.0] * n if rng.random() < 0.5 else [float(rng.choice([1.0, -1.0])) for _ in range(n)]
+    if rng.random() < 0.25:
+        metric[int(rng.integers(0, n))] = 0.0            # degenerate: general coefficients, CSR kernel
+
+    def leaf():
+        if rng.random() < 0.5:
+            grades = list(range(n + 1))
+        else:
+            grades = sorted(int(g) for g in rng.choice(n + 1, size=int(rng.integers(3, n + 1)), replace=False))
+        return ("mv", grades, int(rng.integers(0, 2 ** 31)))
+
+    def gen(depth):
+        if depth == 0:
+            return leaf()
+        r = rng.random()
+        if r < 0.55:
+            return ("bin", BIN[int(rng.integers(0, len(BIN)))], gen(depth - 1), gen(depth - 1))
+        if r < 0.70:
+            a = gen(depth - 1)
+            return ("sum", "+" if rng.random() < 0.5 else "-", a, _reseed(rng, a))
+        if r < 0.90:
+            return ("un", UN[int(rng.integers(0, len(UN)))], gen(depth - 1))
+        return ("g", int(rng.integers(0, n + 1)), gen(depth - 1))
+
+    return n, metric, ("bin", "gp", gen(int(rng.integers(0, 2))), gen(int(rng.integers(0, 2))))
+
+
 def random_program(seed):
     """(n, metric, spec)"""
     rng = np.random.default_rng(seed)

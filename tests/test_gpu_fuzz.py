@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import gaast_amd as ga
-from fuzz import random_program, realise
+from fuzz import random_big_program, random_program, realise
 from helpers import HipBackend, OracleBackend
 from oracle import pyoracle as og
 
@@ -84,3 +84,19 @@ def test_random_programs_over_bound_inputs_batched(chunk):
             assert _same_bits(got, want), where
             checked += 1
     assert checked > 0
+
+
+def test_random_big_programs_in_reference_order():
+    """n = 7, 8 with dense leaves: plans of several launches (k_product_ell / k_product_csr, copies, sign flips);
+    GAAST_FLAG_EXACT_ORDER keeps every product in the reference's summation order: bit-exact."""
+    kernels = set()
+    for seed in range(9000, 9024):
+        n, metric, spec = random_big_program(seed)
+        want = realise(spec, OracleBackend(), n).specialize(og.as_algebra(metric)).eval().to_dict()
+        hs = realise(spec, HipBackend(), n).specialize(metric, flags=ga.FLAG_EXACT_ORDER)
+        got = hs.eval().to_dict()
+        kernels.update(l.split("[")[0] for l in hs.launches())
+        assert set(got) == set(want), f"seed {seed}\n{spec}"
+        for k in want:
+            assert _same_bits(got[k], want[k]), f"seed {seed} grade {k}\n{spec}"
+    assert {"product_ell", "product_csr"} <= kernels, kernels
