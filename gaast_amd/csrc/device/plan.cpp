@@ -592,7 +592,13 @@ bool try_fuse(Plan& plan) {
     if (plan.out_layout.row_len == 0) return false;
     const int zero_slot = cursor++;  // one element per item holding +0.0: target of unused MAC slots
     int slab = cursor | 1;  // odd: 64 lanes at one slab offset hit 64 different banks
-    if (slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024) return false;
+    // the LDS interpreter kernel needs the slabs of 64 items in 48 KiB; the hiprtc-specialised kernel keeps the slab
+    // in registers and only needs it to be small enough for that -- plans that fit only the latter are fused
+    // "JIT only" (the runtime falls back to an unfused plan if the compilation fails)
+    const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024);
+    const int jit_slab_limit = plan.dtype == GAAST_F32 ? 200 : 160;
+    const bool jit_allowed = !(plan.flags & GAAST_FLAG_NO_JIT) && slab <= jit_slab_limit;
+    if (!interp_ok && !jit_allowed) return false;
     auto base_of = [&](BufRef r, int canon = 0) {
         return r.kind == BufKind::NODE    ? node_base[size_t(r.idx)]
                : r.kind == BufKind::INPUT ? (canon ? in_base_canon : in_base)[size_t(r.idx)]
@@ -726,7 +732,9 @@ bool try_fuse(Plan& plan) {
     // lane <-> item, every slab element is a local scalar (a register), offsets and signs are
     // constants, the statements are the reference's in the reference's order; the runtime
     // compiles it with -ffp-contract=off so that the roundings stay those of eval.rs:82.
-    if (!(plan.flags & GAAST_FLAG_NO_JIT) && entries <= 8192 && slab <= 160) {
+    if (!interp_ok && entries > 8192) return false;
+    f.fused_jit_only = interp_ok ? 0 : 1;
+    if (jit_allowed && entries <= 8192) {
         std::string src;
         char buf[256];
         const char* ty = plan.dtype == GAAST_F32 ? "float" : "double";

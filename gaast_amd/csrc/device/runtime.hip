@@ -476,6 +476,37 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
     } catch (const std::exception& ex) {
         return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
     }
+    // hiprtc specialisation of fused plans, before anything is uploaded: a plan that can only run as the
+    // specialised kernel is rebuilt without run-time compilation if the compiler is not available
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool rebuild = false;
+        for (Step& s : prog->plan.steps) {
+            if (s.kind != Step::FUSED || s.jit_source.empty()) continue;
+            if (const char* dump = std::getenv("GAAST_DUMP_JIT")) {  // diagnostics: keep the generated source
+                if (FILE* fp = std::fopen(dump, "w")) {
+                    std::fputs(s.jit_source.c_str(), fp);
+                    std::fclose(fp);
+                }
+            }
+            std::string log;
+            const bool ok = std::getenv("GAAST_TEST_HIPRTC_FAILS") ? false : jit_compile(s, &log);
+            if (ok)
+                s.name = "ast_jit" + s.name.substr(s.name.find('['));
+            else if (!log.empty())
+                g_err = "hiprtc: " + log;  // informational: the interpreter kernel (or an unfused plan) runs instead
+            std::string().swap(s.jit_source);
+            if (!ok && s.fused_jit_only) rebuild = true;
+        }
+        if (!rebuild) break;
+        gaast_program_desc d2 = *desc;
+        d2.flags |= GAAST_FLAG_NO_JIT;
+        prog->plan = Plan();
+        try {
+            build_plan(d2, prog->plan);
+        } catch (const std::exception& ex) {
+            return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
+        }
+    }
     Plan& plan = prog->plan;
     for (Step& s : plan.steps) {
         if (int st = upload_vec(s.u32_a, &s.d_a)) return st;
@@ -494,20 +525,6 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         s.coeff_host = s.kind == Step::FUSED ? s.coeff : std::vector<double>();
         std::vector<uint32_t>().swap(s.u32_c);
         std::vector<double>().swap(s.coeff);
-        if (s.kind == Step::FUSED && !s.jit_source.empty()) {
-            if (const char* dump = std::getenv("GAAST_DUMP_JIT")) {  // diagnostics: keep the generated source
-                if (FILE* fp = std::fopen(dump, "w")) {
-                    std::fputs(s.jit_source.c_str(), fp);
-                    std::fclose(fp);
-                }
-            }
-            std::string log;
-            if (jit_compile(s, &log))
-                s.name = "ast_jit" + s.name.substr(s.name.find('['));
-            else if (!log.empty())
-                g_err = "hiprtc: " + log;  // informational: the interpreter kernel runs instead
-            std::string().swap(s.jit_source);
-        }
         prog->launch_names.push_back(s.name);
     }
     prog->const_mvs.assign(plan.inputs.size(), nullptr);
