@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched evaluation of one SpecializedAst on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r12d|r12ds|r12x|r8|r8d|r8s|r8x|cl41]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r12|r12s|r12d|r12ds|r12x|r8|r8d|r8s|r8x|cl41|cl41g1|cl41s|gpN{f32,f64}[s|x]]
 
 A "step" is one pass of the hot path (gaast_hip_eval) over one batch of synthetic input
 multivectors already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
@@ -104,6 +104,16 @@ def workload_spec(name):
                     inputs=[[0, 2, 4], [1]], build=lambda r, x: r * x * r.rev(), entries=80 + 256,
                     default_batch=1 << 22,
                     label="R^{4,1} rotor sandwich R X ~R, f64 (BASELINE configs[4])")
+    if name == "cl41g1":    # the same sandwich projected on grade 1 (tables 80 + 80, 5 result components)
+        return dict(n=5, metric=[1.0, 1.0, 1.0, 1.0, -1.0], dtype=ga.F64, dtname="f64",
+                    inputs=[[0, 2, 4], [1]], build=lambda r, x: (r * x * r.rev()).g(1), entries=80 + 80,
+                    default_batch=1 << 22,
+                    label="R^{4,1} rotor sandwich (R X ~R).g(1), f64")
+    if name == "cl41s":     # one rotor shared by every item (batch-1 input): 40 B in, 128 B out per item
+        return dict(n=5, metric=[1.0, 1.0, 1.0, 1.0, -1.0], dtype=ga.F64, dtname="f64",
+                    inputs=[[0, 2, 4], [1]], shared=[0], build=lambda r, x: r * x * r.rev(), entries=80 + 256,
+                    default_batch=1 << 22,
+                    label="R^{4,1} rotor sandwich R X ~R with one shared rotor, f64")
     import re
     m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order)
     if m:
@@ -264,9 +274,10 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(3 + rank)
     ins, in_t = [], []
-    for g in wl["inputs"]:
+    for slot, g in enumerate(wl["inputs"]):
         rl = ga.graded.row_len(n, ga.graded._mask_of(g))
-        t = torch.rand((batch, rl), generator=gen, device=dev, dtype=tdt) * 2 - 1
+        nb = 1 if slot in wl.get("shared", []) else batch          # a batch-1 input is shared by every item
+        t = torch.rand((nb, rl), generator=gen, device=dev, dtype=tdt) * 2 - 1
         in_t.append(t)
         ins.append(ga.DeviceMV.wrap_tensor(t, n, g))
     out_t = torch.empty((batch, out_len), device=dev, dtype=tdt)
@@ -342,7 +353,7 @@ def main():
         items_total = batch * world * args.steps
         value = items_total / wall
         sz = 4 if dtype == ga.F32 else 8
-        in_len = sum(t.shape[1] for t in in_t)
+        in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)      # shared inputs are read once, not per item
         bytes_item = (in_len + out_len) * sz          # every input/output component touched once
         # one multiply + one add per comp-mul entry (the matrix-representation kernel: what it executes)
         flops_item = wl.get("flops_item", 2 * wl["entries"])
