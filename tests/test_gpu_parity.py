@@ -239,6 +239,19 @@ def test_exact_order_dense_product_is_bit_exact(n, neg, batch):
     assert hmask == omask and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,left_grades", [(7, [0, 1, 2]), (8, [0, 1, 2, 3])])
+def test_exact_order_uniform_rows_of_odd_width(n, left_grades):
+    """rows of 29 / 93 entries: the 32-word chunks of k_product_ell plus its remainder loop"""
+    batch = 13
+    rng = np.random.default_rng(95 + n)
+    build = lambda B: B.input(0, left_grades, n) * B.input(1, full_grades(n), n)
+    rows = {0: rows_of(n, left_grades, batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    want, omask = oracle_eval_batch(build, n, rows, batch)
+    got, hmask, spec = hip_eval_batch(build, n, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+    assert any("product_ell" in l for l in spec.launches()), spec.launches()
+    assert hmask == omask and np.array_equal(got, want)
+
+
 def test_exact_order_sum_of_dense_products_accumulates_bit_exact():
     """a*b + c*d: the second product adds into the buffer the first one wrote (beta = 1), reference order"""
     n, batch = 8, 11
