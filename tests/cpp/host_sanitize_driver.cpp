@@ -113,6 +113,28 @@ int main() {
         lower(e2, 12, euclid, GAAST_F32, GAAST_FLAG_SPINOR_GEMM, "matrix representation n=12 partial", "product_spinor_gemm");
         lower(e2, 12, euclid, GAAST_F32, 0, "dense n=12 partial", "product_dense");
     }
+    for (int n : {7, 8, 9}) {   // reference-order dense products: CSR -> transposed [term][row] list (k_product_ell)
+        gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
+        gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
+        char what[64];
+        std::snprintf(what, sizeof what, "exact order n=%d f64", n);
+        lower(e, n, euclid, GAAST_F64, GAAST_FLAG_EXACT_ORDER, what, "product_ell");
+        std::snprintf(what, sizeof what, "exact order n=%d f32", n);
+        lower(e, n, euclid, GAAST_F32, GAAST_FLAG_EXACT_ORDER, what, "product_ell");
+        // rows of 1 + n + C(n,2) entries: not a multiple of the kernel's chunk
+        gaast_expr_t lowg = gaast_expr_input(2, 0x7, n);
+        lower(gaast_expr_product(lowg, b, GAAST_PROD_GEOMETRIC), n, euclid, GAAST_F64, GAAST_FLAG_EXACT_ORDER, "exact order, odd width", "product_ell");
+    }
+    {   // degenerate metric: 0.0 coefficients stay in the CSR list
+        const double pga7[7] = {0, 1, 1, 1, 1, 1, 1};
+        gaast_expr_t a = gaast_expr_input(0, full_mask(7), 7), b = gaast_expr_input(1, full_mask(7), 7);
+        lower(gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC), 7, pga7, GAAST_F64, GAAST_FLAG_EXACT_ORDER, "exact order, degenerate", "product_csr");
+    }
+    {   // fused for the specialised kernel only (slab too big for the LDS interpreter)
+        gaast_expr_t a = gaast_expr_input(0, full_mask(5), 5), b = gaast_expr_input(1, full_mask(5), 5);
+        lower(gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC), 5, euclid, GAAST_F64, 0, "r5 f64, JIT-only fusion", "ast_");
+        lower(gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC), 5, euclid, GAAST_F64, GAAST_FLAG_NO_JIT, "r5 f64 without JIT", "product_ell");
+    }
     {   // the other products and unary arms on R^4
         gaast_expr_t a = gaast_expr_input(0, full_mask(4), 4), b = gaast_expr_input(1, full_mask(4), 4);
         for (int kind : {GAAST_PROD_OUTER, GAAST_PROD_INNER, GAAST_PROD_LCONTRACT, GAAST_PROD_RCONTRACT})
