@@ -487,4 +487,123 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Matrix-core form for n = 8, 9 (f32): v_mfma_f32_16x16x1_4b_f32, four independent 16 x 16 outer products
+// per instruction.  With lo = 4 bits the contribution of block a_hi to the 16 result columns c_hi of a tile is
+// a 16 x 16 x 16 GEMM per ITEM; the four blocks of the instruction are four items, so one wave owns all
+// 16 x 16 results (n = 8; half of them at n = 9) of four items:
+//   lane 16 b + i:  A operand = +-A_b[a_hi][i ^ k]   (gather, lane-constant offset and sign per k)
+//                   B operand = +-B_b[a_hi ^ c_hi(i)][k]   (the lane's block, 4 ds_read_b128 per step)
+//   16 instructions (k = 0..15) per step.  Same sums as k_gp_mfma32 / k_gp_dense: a k-ordered fmaf chain.
+// Operand images: A in plain blade order, B in the vector kernel's quad-rotated order; items are 2^(n+1) + 16
+// words apart so that the four items of a wave sit on different banks.
+// ------------------------------------------------------------------------------------------
+template <bool DEGENERATE, int NDIM>
+__global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    constexpr int n = NDIM;                       // 8 or 9
+    constexpr int N = 1 << n;
+    constexpr int H = 1 << (n - 4);               // number of 16-blocks
+    constexpr int WPG = H >> 4;                       // waves per group of four items (16 result columns each)
+    constexpr int GPB = 4 / WPG;                  // groups per workgroup
+    constexpr int IPB = 4 * GPB;                  // items per workgroup
+    constexpr int item_stride = 2 * N + 16;
+    const int tid = threadIdx.x;
+    const int64_t item0 = int64_t(blockIdx.x) * IPB;
+    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+
+    if (!p.left_full || !p.right_full) {
+        for (int i = tid; i < nitems * item_stride; i += 256) smem[i] = 0.f;
+        __syncthreads();
+    }
+    stage_operands<float, 256>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                               p.canon_left, smem, item_stride, nitems, tid);
+    stage_operands<float, 256>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                               p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int grp = wave / WPG, tile = wave - grp * WPG;
+    const int blk = lane >> 4, i = lane & 15;
+    const int it = grp * 4 + blk;                 // this lane's item (operand side); may be beyond nitems: not stored
+    const float* As = smem + it * item_stride;
+    const float* Bs = As + N;
+    const int c_hi = (tile << 4) | i;
+
+    uint32_t amask[16], aoff[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int a_lo = i ^ k;
+        int par = 0;
+        for (int pp = 1; pp < 4; ++pp)
+            if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+        amask[k] = uint32_t(par) << 31;
+        aoff[k] = uint32_t(a_lo) << 2;
+    }
+    float16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
+    auto one_step = [&](int a_hi) {
+        uint32_t sp = uint32_t(a_hi) >> 1;
+        sp ^= sp >> 1;
+        sp ^= sp >> 2;
+        sp ^= sp >> 4;
+        sp ^= sp >> 8;
+        const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+        const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                            __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+        const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
+        float bscale = 1.f;
+        if (DEGENERATE) {
+            if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
+        }
+        const int x = a_hi ^ c_hi;
+        const int rot = (x >> 2) & 3;             // dense_lds_pos: quads of block x rotated by (x >> 2) & 3
+        const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 4));
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v v = bp[q ^ rot];
+            bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+        }
+        const uint32_t abase = uint32_t(a_hi) << 6;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a = *reinterpret_cast<const float*>(As_b + abase + aoff[k]);
+            a = __uint_as_float(__float_as_uint(a) ^ amask[k]);
+            float b = __uint_as_float(__float_as_uint(bv[k]) ^ bmask);
+            if (DEGENERATE) b *= bscale;
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0);
+        }
+    };
+    // (unrolling this loop makes the block index a constant but costs all the registers: 1 wave per SIMD, -40 %)
+    constexpr int half = H >> 1;
+#pragma unroll 1
+    for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
+#pragma unroll
+    for (int k = 0; k < 16; ++k)  // (-1)^(|a_hi| |k|) for odd |a_hi|
+        amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
+#pragma unroll 1
+    for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+
+    // ---- results: register 4 b + r of lane 16 rg + j = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + j ----
+    const int rg = lane >> 4;
+    const int32_t* om = p.out_map + (c_hi << 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int item = grp * 4 + b;
+        if (item < nitems) {
+            float* orow = p.out + (item0 + item) * p.out_stride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t off = om[4 * rg + r];
+                if (off >= 0) orow[off] = p.beta ? orow[off] + acc[4 * b + r] : acc[4 * b + r];
+            }
+        }
+    }
+}
+
 }  // namespace gaast

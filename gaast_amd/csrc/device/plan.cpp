@@ -420,6 +420,8 @@ struct Lowering {
             // matrix-core variant: f32, n >= 10 (32 result columns per wave), low FIVE vectors +1
             s.use_mfma = plan.dtype == GAAST_F32 && n >= 10 && n <= 13 && d.metric_diag[4] == 1.0 &&
                          !(plan.flags & GAAST_FLAG_NO_MFMA);
+            // 16 x 16 four-block matrix-core variant: f32, n = 8, 9 (four items per wave)
+            s.use_mfma16 = plan.dtype == GAAST_F32 && (n == 8 || n == 9) && !(plan.flags & GAAST_FLAG_NO_MFMA);
             // position of blade m in the LDS image the kernel reads (mirrors kernels.hip.hpp)
             auto vec_pos = [](uint32_t m) {  // dense_lds_pos
                 const uint32_t x = m >> 4, lo = m & 15;
@@ -439,7 +441,8 @@ struct Lowering {
                     const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
                         const uint32_t blade = bt.blade_of[size_t(k)][i];
-                        const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade) : vec_pos(blade);
+                        const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
+                                             : s.use_mfma16 ? (right ? vec_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();
                         map.push_back(off | (pos << 16) | sgn);
@@ -461,7 +464,7 @@ struct Lowering {
                 if (d.metric_diag[i] == 0.0) s.zero_hi |= 1u << (i - lo_bits);
             }
             s.degenerate = s.zero_hi != 0;
-            if (s.use_mfma) s.name = "product_dense_mfma[gp n=" + std::to_string(n) + "]";
+            if (s.use_mfma || s.use_mfma16) s.name = "product_dense_mfma[gp n=" + std::to_string(n) + "]";
             touch(res);
             return;
         }

@@ -306,6 +306,18 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
                 break;
             }
         }
+        if (s.use_mfma16) {
+            if constexpr (std::is_same<T, float>::value) {
+                const int wpg = 1 << (n - 8);                  // waves per group of four items
+                const int ipb = 4 * (4 / wpg);
+                const size_t lds = size_t(ipb) * size_t((2 << n) + 16) * sizeof(float);
+                auto kern = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8> : &k_gp_mfma16<false, 8>)
+                                   : (s.degenerate ? &k_gp_mfma16<true, 9> : &k_gp_mfma16<false, 9>);
+                const int64_t blocks = (batch + ipb - 1) / ipb;
+                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(256), lds, g_stream, p);
+                break;
+            }
+        }
         const int lpi = 1 << (n - 4);
         const int threads = lpi > 256 ? lpi : 256;
         const int ipb = threads / lpi;

@@ -174,6 +174,25 @@ def test_dense_gp_mixed_signature(metric):
         assert np.all(np.abs(got[i] - want[i]) <= bound)
 
 
+@pytest.mark.parametrize("n,metric", [(8, [1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, 1.0]), (8, [1.0, 1.0, 1.0, 1.0, 0.0, 1.0, -1.0, 0.0]),
+                                      (9, [1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 0.0, 1.0])])
+def test_dense_mfma16_mixed_and_degenerate_signatures_f32(n, metric):
+    """k_gp_mfma16 (four items per wave): negative and null basis vectors among the hi bits, a batch that does not
+    fill the last workgroup, and the vector-FMA kernel (GAAST_FLAG_NO_MFMA) as a second opinion"""
+    batch = 37
+    rng = np.random.default_rng(70 + n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    want, _ = oracle_eval_batch(_gp(n), metric, rows, batch)
+    got, _, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32)
+    assert any("product_dense_mfma" in l for l in spec.launches()), spec.launches()
+    alt, _, spec2 = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_NO_MFMA)
+    assert any(l.startswith("product_dense[") for l in spec2.launches()), spec2.launches()
+    for i in range(batch):
+        bound = _dense_bound(n, np.abs(metric), rows[0][i], rows[1][i], 2.0 ** -23)
+        assert np.all(np.abs(got[i].astype(np.float64) - want[i]) <= bound), i
+        assert np.all(np.abs(alt[i].astype(np.float64) - want[i]) <= bound), i
+
+
 def test_dense_gp_partial_grades_and_projection():
     """even * full -> grades {1,3,5}: absent operand grades are zeros, unwanted outputs dropped."""
     n = 7
