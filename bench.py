@@ -33,7 +33,7 @@ PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 # WRITE_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md): (workload, batch) -> bytes
 PMC_TRAFFIC = {("r12s", 65536): (2 * 1.04883e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r12s_pmc_counters.csv"),
                ("r12", 65536): (2 * 1.04889e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r12_mfma_pmc_counters.csv"),
-               ("r8", 1 << 20): (2 * 1048694.5 * 1024 + 1048861.1 * 1024, "profiles/r01_r8_pmc_counters.csv"),
+               ("r8", 1 << 20): (2 * 1.04869e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r8_pmc_counters.csv"),
                ("cl41g1", 1 << 22): (2 * 344100 * 1024 + 163853 * 1024, "profiles/r01_cl41g1_pmc_counters.csv"),
                ("cl41", 1 << 22): (2 * 344497.1 * 1024 + 524352.1 * 1024, "profiles/r01_cl41_pmc_counters.csv")}
 
