@@ -29,14 +29,6 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 
-# HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 x 1024 +
-# WRITE_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md): (workload, batch) -> bytes
-PMC_TRAFFIC = {("r12s", 65536): (2 * 1.04883e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r12s_pmc_counters.csv"),
-               ("r12", 65536): (2 * 1.04889e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r12_mfma_pmc_counters.csv"),
-               ("r8", 1 << 20): (2 * 1.04869e6 * 1024 + 1.04858e6 * 1024, "profiles/r01_r8_pmc_counters.csv"),
-               ("cl41g1", 1 << 22): (2 * 344100 * 1024 + 163853 * 1024, "profiles/r01_cl41g1_pmc_counters.csv"),
-               ("cl41", 1 << 22): (2 * 344497.1 * 1024 + 524352.1 * 1024, "profiles/r01_cl41_pmc_counters.csv")}
-
 
 def workload_spec(name):
     """(n, metric, dtype name, builder, input grade lists, label)"""
@@ -214,32 +206,65 @@ def cpu_baseline(wl, budget_s=12.0):
     return out
 
 
+def _load_traffic_table():
+    """profiles/traffic.json: HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_traffic.py writes it from
+    the raw counter CSVs): {"<workload>:<batch>": {"kernel": ..., "bytes": ..., "source": ...}}"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _traffic_for(workload, batch, kernel_names):
+    """(bytes per launch or None, source or None, stale flag).  A counter recorded for another kernel than the one this
+    run launched is NOT reported: traffic = None, traffic_stale = True."""
+    import gaast_amd as ga
+    ent = _load_traffic_table().get(f"{workload}:{batch}")
+    if not ent:
+        return None, None, False
+    if ent["kernel"] not in kernel_names or ent.get("library") != ga.lib().gaast_hip_version().decode():
+        return None, ent.get("source"), True
+    return ent["bytes"], ent.get("source"), False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="r12")
-    ap.add_argument("--batch", type=int, default=0, help="input sets per GPU (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=0, help="input sets per GPU (default: the workload's; with --gpus N > 1 "
+                    "and the default workload: BASELINE configs[3], 1,048,576 input sets over all GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-chunks", type=int, default=4)
     ap.add_argument("--no-alt", action="store_true", help="skip the opt-in matrix-representation side measurement")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-item latency side measurement")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import gaast_amd as ga
+    # `python bench.py --gpus N` with no launcher: start the N ranks ourselves, BEFORE anything touches a GPU
+    # (this parent never imports torch; it waits for the ranks and exits with their status)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from gaast_amd.launch import self_launch
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # CPU baseline first (rank 0, N = 1 only): its all-cores leg forks workers, which must happen before
     # this process initialises the GPU
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(workload_spec(args.workload))
+
+    import torch
+    import torch.distributed as dist
+    import gaast_amd as ga
+    from gaast_amd.sharding import max_over_ranks, shard_range
+
     # GAAST_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a box with fewer GPUs than ranks (ranks
     # share devices, collectives go through gloo on host copies).  Never set by the driver; numbers
     # from such a run are not measurements.
@@ -248,6 +273,8 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = None
+    lib_comm = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -255,12 +282,55 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     ga.init_device(local_rank)
+    L = ga.lib()
     stream = torch.cuda.current_stream()
-    ga._lib.check(ga.lib().gaast_hip_set_stream(C.c_void_p(stream.cuda_stream)))
+    ga._lib.check(L.gaast_hip_set_stream(C.c_void_p(stream.cuda_stream)))
+    if world > 1:
+        # how many ranks the collective library really joined (an all-reduce of ones)
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if not rehearsal:
+            # the library's own communicator (what a Rust host would use: include/gaast_hip.h, multi-GPU): the
+            # 128-byte id travels over the rendezvous torch.distributed already provides
+            idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)()
+            if rank == 0:
+                ga._lib.check(L.gaast_hip_comm_unique_id(idbuf))
+            idt = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+            dist.broadcast(idt, src=0)
+            idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)(*idt.cpu().tolist())
+            ga._lib.check(L.gaast_hip_comm_init(idbuf, rank, world))
+            nr = C.c_int()
+            ga._lib.check(L.gaast_hip_comm_count_ranks(C.byref(nr)))
+            lib_comm = nr.value == world
+            rccl_ranks = min(rccl_ranks, nr.value)
 
     wl = workload_spec(args.workload)
     n, dtype = wl["n"], wl["dtype"]
-    batch = args.batch or wl["default_batch"]
+    label = wl["label"]
+    scaling = "weak"
+    if args.batch:
+        batch = args.batch
+        global_batch = batch * world
+        first = rank * batch
+    elif world > 1 and args.workload == "r12":
+        # BASELINE configs[3]: 1,048,576 input sets, contiguous shards of ceil(B / g) items per GPU
+        global_batch = 1 << 20
+        first, stop = shard_range(global_batch, rank, world)
+        batch = stop - first
+        label = f"R^12 full MV x MV geometric product, f32, 1,048,576 input sets sharded over {world} GPUs (BASELINE configs[3])"
+        scaling = "strong"
+    else:
+        batch = wl["default_batch"]
+        global_batch = batch * world
+        first = rank * batch
+    counts = [batch] * world
+    if world > 1:
+        ct = torch.tensor([batch], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        cl = [torch.zeros_like(ct) for _ in range(world)]
+        dist.all_gather(cl, ct)
+        counts = [int(c.item()) for c in cl]
+        global_batch = sum(counts)
     tdt = torch.float32 if dtype == ga.F32 else torch.float64
 
     # one SpecializedAst (phases 1-3 on the host, once), one device program
@@ -271,17 +341,27 @@ def main():
     t_spec = time.time() - t0
     out_mask, out_len = spec.output_info()
 
-    # synthetic inputs, generated on the device: item i of rank r is seeded by (seed, r)
+    # synthetic inputs, generated on the device: the shard of rank r is seeded by (seed, r)
     gen = torch.Generator(device=dev)
     gen.manual_seed(3 + rank)
     ins, in_t = [], []
     for slot, g in enumerate(wl["inputs"]):
         rl = ga.graded.row_len(n, ga.graded._mask_of(g))
         nb = 1 if slot in wl.get("shared", []) else batch          # a batch-1 input is shared by every item
-        t = torch.rand((nb, rl), generator=gen, device=dev, dtype=tdt) * 2 - 1
+        t = torch.empty((nb, rl), device=dev, dtype=tdt)
+        for lo in range(0, nb, 1 << 16):                           # in slices: no multi-GiB temporaries
+            t[lo:lo + (1 << 16)].uniform_(-1, 1, generator=gen)
         in_t.append(t)
         ins.append(ga.DeviceMV.wrap_tensor(t, n, g))
-    out_t = torch.empty((batch, out_len), device=dev, dtype=tdt)
+    # the root's result rows live inside the gathered buffer (no local copy at gather time)
+    gathered_t = gathered = None
+    want_gather = world > 1 and not args.no_gather
+    if want_gather and rank == 0 and not rehearsal:
+        gathered_t = torch.empty((global_batch, out_len), device=dev, dtype=tdt)
+        gathered = ga.DeviceMV.wrap_tensor(gathered_t, n, ga.GradeSet(out_mask))
+        out_t = gathered_t[:batch]
+    else:
+        out_t = torch.empty((batch, out_len), device=dev, dtype=tdt)
     out = ga.DeviceMV.wrap_tensor(out_t, n, ga.GradeSet(out_mask))
 
     def step():
@@ -292,6 +372,18 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        """wall seconds of `steps` calls between fences, max over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        if lib_comm:
+            ga._lib.check(L.gaast_hip_synchronize())
+        fence()
+        w = time.perf_counter() - t0
+        return max_over_ranks(w, device=None if rehearsal else dev) if world > 1 else w
 
     for _ in range(args.warmup):
         step()
@@ -305,7 +397,6 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     if world > 1:
-        from gaast_amd.sharding import max_over_ranks
         wall = max_over_ranks(wall, device=None if rehearsal else dev)
     step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     kernel_ms = sum(step_ms) / len(step_ms)
@@ -330,28 +421,101 @@ def main():
         sl = slice(0, min(batch, 4096))
         diff = (out_alt_t[sl].double() - out_t[sl].double()).abs().max().item()
         scale = (in_t[0][sl].double().norm(dim=1) * in_t[1][sl].double().norm(dim=1)).max().item()
+        alt_flops = 3 * 2 * (1 << (n // 2)) ** 3
+        sz_a = 4 if dtype == ga.F32 else 8
         alt = {"kernel": [l for l in spec_alt.launches() if "product" in l][-1], "value": batch / (alt_ms * 1e-3),
-               "unit": "products/s", "kernel_ms": alt_ms, "algorithmic_GBps": batch * 3 * (1 << n) * (4 if dtype == ga.F32 else 8) / (alt_ms * 1e-3) * 1e-9,
-               "mfma_TFLOPs": batch * (3 * 2 * (1 << (n // 2)) ** 3) / (alt_ms * 1e-3) * 1e-12,
+               "unit": "products/s", "kernel_ms": alt_ms, "algorithmic_GBps": batch * 3 * (1 << n) * sz_a / (alt_ms * 1e-3) * 1e-9,
+               "mfma_TFLOPs": batch * alt_flops / (alt_ms * 1e-3) * 1e-12,
+               "frac_of_hbm_roof": batch * 3 * (1 << n) * sz_a / (alt_ms * 1e-3) * 1e-9 / PEAK_HBM_GBPS,
+               "frac_of_mfma_roof": batch * alt_flops / (alt_ms * 1e-3) * 1e-12 / (PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS),
                "max_abs_diff_vs_default_path": diff, "diff_over_eps_normA_normB": diff / ((2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52) * scale),
                "note": f"opt-in GAAST_FLAG_SPINOR_GEMM: {1 << (n // 2)}x{1 << (n // 2)} complex matrix representation, 3 real MFMA products per item; "
                        "norm-wise error bound, not the reference's summation order"}
         del out_alt_t, out_alt, spec_alt
 
-    # final gather of the result shards to rank 0 over RCCL (xGMI), outside the timed region
-    gather_ms = None
-    if world > 1 and not args.no_gather:
-        send = out_t.cpu() if rehearsal else out_t
-        glist = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        fence()
-        g0 = time.perf_counter()
-        dist.gather(send, glist, dst=0)
-        fence()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        del glist
+    # what the reference actually does -- ONE input set per eval(): latency of a batch-1 evaluation through the
+    # C ABI (program built once; launch + kernel + synchronize), beside the batched throughput
+    latency = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        one_in = [ga.DeviceMV.wrap_tensor(t[:1], n, g) for t, g in zip(in_t, wl["inputs"])]
+        one_out_t = torch.empty((1, out_len), device=dev, dtype=tdt)
+        one_out = ga.DeviceMV.wrap_tensor(one_out_t, n, ga.GradeSet(out_mask))
+        for _ in range(3):
+            spec.eval_batch(one_in, 1, out=one_out)
+        torch.cuda.synchronize()
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            spec.eval_batch(one_in, 1, out=one_out)
+            torch.cuda.synchronize()
+        latency = {"batch": 1, "ms_per_eval": (time.perf_counter() - t0) / reps * 1e3, "program_create_s": t_spec,
+                   "note": "one gaast_hip_eval of one input set + synchronize (the reference evaluates one input set per "
+                           "eval()); the program is built once per SpecializedAst"}
+
+    # the one exchange of the path: result rows to rank 0.  Measured twice over the same K steps:
+    #   blocking   eval, then gaast_hip_gather_rows (one transfer per peer, all links at once)
+    #   overlapped gaast_hip_eval_gather: the shard in `chunks` chunks, chunk k travels while chunk k + 1 computes
+    gather = None
+    if want_gather:
+        sz = 4 if dtype == ga.F32 else 8
+        chunks = max(1, args.gather_chunks)
+        cnt = (C.c_int64 * world)(*counts)
+        if lib_comm:
+            def blocking():
+                spec.eval_batch(ins, batch, out=out)
+                ga._lib.check(L.gaast_hip_gather_rows(out._h, gathered._h if gathered is not None else None, cnt, 0))
+
+            def overlapped():
+                spec.eval_gather(ins, out, gathered, counts, root=0, n_chunks=chunks)
+            path = "gaast_hip_eval_gather / gaast_hip_gather_rows: RCCL send/recv, one direct transfer per peer"
+        else:
+            # rehearsal (ranks share a GPU, RCCL refuses that) or no library communicator: the same chunk schedule with
+            # torch.distributed collectives on host copies
+            from gaast_amd.sharding import chunk_span
+            per = max(counts)
+            def _gather_span(lo, hi, async_op):
+                send = torch.zeros((-(-per // chunks) if async_op else per, out_len), dtype=tdt)
+                send[:hi - lo] = out_t[lo:hi].cpu()
+                bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+                return dist.gather(send, bufs, dst=0, async_op=async_op), bufs
+
+            def blocking():
+                spec.eval_batch(ins, batch, out=out)
+                torch.cuda.synchronize()
+                _gather_span(0, batch, False)
+
+            def overlapped():
+                pend = []
+                for c in range(chunks):
+                    lo, hi = chunk_span(batch, chunks, c)
+                    sub_in = [ga.DeviceMV.wrap_tensor(t[lo:hi] if t.shape[0] == batch else t, n, g) for t, g in zip(in_t, wl["inputs"])]
+                    sub_out = ga.DeviceMV.wrap_tensor(out_t[lo:hi], n, ga.GradeSet(out_mask))
+                    if hi > lo:
+                        spec.eval_batch(sub_in, hi - lo, out=sub_out)
+                    torch.cuda.synchronize()
+                    pend.append(_gather_span(lo, hi, True))
+                for h, _ in pend:
+                    h.wait()
+            path = "torch.distributed gather of host copies (rehearsal: ranks share a GPU)" if rehearsal else "torch.distributed gather (library communicator unavailable)"
+        blocking()
+        overlapped()
+        w_block = timed(blocking, args.steps)
+        w_over = timed(overlapped, args.steps)
+        items_total = global_batch * args.steps
+        gather = {"path": path, "chunks": chunks, "bytes_per_rank": out_len * sz * batch, "bytes_total": out_len * sz * global_batch,
+                  "ms_per_step_eval_only": wall / args.steps * 1e3,
+                  "ms_per_step_blocking_gather": w_block / args.steps * 1e3,
+                  "ms_per_step_overlapped_gather": w_over / args.steps * 1e3,
+                  "value_without_gather": items_total / wall,
+                  "value_with_blocking_gather": items_total / w_block,
+                  "value_with_gather": items_total / w_over,
+                  "ms": max(0.0, (w_block - wall) / args.steps * 1e3)}
+        if rank == 0 and gathered_t is not None:
+            # the gathered rows of the LAST rank equal what that rank computed (spot check through a second gather)
+            gather["gathered_rows"] = int(gathered_t.shape[0])
 
     if rank == 0:
-        items_total = batch * world * args.steps
+        items_total = global_batch * args.steps
         value = items_total / wall
         sz = 4 if dtype == ga.F32 else 8
         in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)      # shared inputs are read once, not per item
@@ -372,35 +536,40 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
                     "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
-        pmc = PMC_TRAFFIC.get((args.workload, batch))
-        roof["traffic"] = pmc[0] if pmc else None
-        roof["traffic_source"] = pmc[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if pmc else None
-        roof["algorithmic_bytes_per_launch"] = bytes_item * batch
         roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
+        traffic, source, stale = _traffic_for(args.workload, batch, [roof["kernel"]])
+        roof["traffic"] = traffic
+        roof["traffic_source"] = source
+        roof["traffic_stale"] = stale
+        roof["algorithmic_bytes_per_launch"] = bytes_item * batch
         roof["kernel_ms"] = kernel_ms
         roof["flops_per_item"] = flops_item
         roof["bytes_per_item"] = bytes_item
         res = {
             "metric": "full-MV geometric products/sec (dim n); achieved HBM GB/s vs roofline",
             "value": value, "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": wl["dtname"], "data": "synthetic",
+            "global_batch": global_batch,
+            **({"rccl_ranks": rccl_ranks} if world > 1 else {}),
             **({"rehearsal": "ranks share GPUs, gloo collectives: control-flow check only, not a measurement"} if rehearsal else {}),
-            "config": {"workload": wl["label"], "dim": n, "batch_per_gpu": batch, "global_batch": batch * world,
-                       "launches_per_eval": launches, "specialize_s": t_spec},
+            "config": {"workload": label, "dim": n, "batch_per_gpu": batch, "global_batch": global_batch,
+                       "shards": counts, "launches_per_eval": launches, "specialize_s": t_spec},
             "roofline": roof,
         }
         if alt is not None:
             res["matrix_representation"] = alt
-        if gather_ms is not None:
-            out_bytes = out_len * sz * batch
-            res["gather"] = {"ms": gather_ms, "bytes_per_rank": out_bytes,
-                             "value_with_gather": items_total / (wall + gather_ms * 1e-3 * args.steps)}
+        if latency is not None:
+            res["single_item_latency"] = latency
+        if gather is not None:
+            res["gather"] = gather
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
+        if lib_comm:
+            L.gaast_hip_comm_destroy()
         dist.destroy_process_group()
 
 

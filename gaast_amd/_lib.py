@@ -22,6 +22,8 @@ OP_NAMES = ["GradedObj", "Addition", "Product", "Negation", "Exponential", "Loga
             "GradeProjection", "Reverse", "GradeInvolution", "ScalarInversion", "ScalarSqrt"]
 PROD_EXPLICIT, PROD_GEOMETRIC, PROD_OUTER, PROD_INNER, PROD_LCONTRACT, PROD_RCONTRACT = -1, 0, 1, 2, 3, 4
 FLAG_DEBUG_OVERFLOW, FLAG_NO_FUSION, FLAG_EXACT_ORDER, FLAG_NO_MFMA, FLAG_NO_JIT, FLAG_SPINOR_GEMM = 1, 2, 4, 8, 16, 32
+FLAG_DEBUG_JIT_FAILS, FLAG_DEBUG_KEEP_JIT_SOURCE, FLAG_EXP_LOG = 0x40, 0x80, 0x100
+COMM_ID_BYTES = 128
 
 
 class GaastError(RuntimeError):
@@ -94,6 +96,14 @@ SIGNATURES = {
     "gaast_hip_mv_download_rows": (_ci, [_vp, _vp, _i64]),
     "gaast_hip_mv_zero": (_ci, [_vp]),
     "gaast_hip_eval": (_ci, [_vp, C.POINTER(_vp), _ci, _i64, _vp]),
+    "gaast_hip_program_jit_source": (C.c_char_p, [_vp]),
+    "gaast_hip_comm_unique_id": (_ci, [_vp]),
+    "gaast_hip_comm_init": (_ci, [_vp, _ci, _ci]),
+    "gaast_hip_comm_destroy": (_ci, []),
+    "gaast_hip_comm_info": (_ci, [C.POINTER(_ci), C.POINTER(_ci)]),
+    "gaast_hip_comm_count_ranks": (_ci, [C.POINTER(_ci)]),
+    "gaast_hip_gather_rows": (_ci, [_vp, _vp, C.POINTER(_i64), _ci]),
+    "gaast_hip_eval_gather": (_ci, [_vp, C.POINTER(_vp), _ci, _vp, _vp, C.POINTER(_i64), _ci, _ci]),
     # ---- include/gaast_expr.h ----
     "gaast_expr_last_error": (C.c_char_p, []),
     "gaast_gs_single": (_u64, [_i64]),

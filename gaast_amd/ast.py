@@ -176,6 +176,9 @@ class SpecializedAst:
         if not self._p:
             raise _lib.GaastError(1, L.gaast_expr_last_error().decode())
         self._prog = None
+        self._n_slots = None
+        self._out_info = None
+        self._input_descs = None
 
     def __del__(self):
         try:
@@ -239,9 +242,37 @@ class SpecializedAst:
         return self._prog
 
     def output_info(self):
-        mask, rl = C.c_uint64(), C.c_int64()
-        _lib.check(_lib.lib().gaast_hip_program_output_info(self.program(), C.byref(mask), C.byref(rl)))
-        return mask.value, rl.value
+        if self._out_info is None:
+            mask, rl = C.c_uint64(), C.c_int64()
+            _lib.check(_lib.lib().gaast_hip_program_output_info(self.program(), C.byref(mask), C.byref(rl)))
+            self._out_info = (mask.value, rl.value)
+        return self._out_info
+
+    def jit_source(self):
+        """GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE: the HIP source hiprtc compiled for this program."""
+        return _lib.lib().gaast_hip_program_jit_source(self.program()).decode()
+
+    def _bind(self, inputs):
+        """inputs -> (handle array, n_slots, objects to keep alive); host arrays are uploaded."""
+        L = _lib.lib()
+        if self._n_slots is None:
+            self._n_slots = L.gaast_spec_num_inputs(self._p)
+        n_slots = self._n_slots
+        handles = (C.c_void_p * max(1, n_slots))()
+        keep = []
+        for slot in range(min(len(inputs), n_slots)):
+            x = inputs[slot]
+            if x is None:
+                continue
+            if not isinstance(x, DeviceMV):
+                if self._input_descs is None:    # only a host array needs the slot's layout
+                    d = self.program_desc()
+                    self._input_descs = [(d.inputs[i].storage_dim, d.inputs[i].grade_mask) for i in range(d.n_inputs)]
+                sdim, smask = self._input_descs[slot]
+                x = DeviceMV.from_rows(sdim, GradeSet(smask), x, self.dtype)
+            keep.append(x)
+            handles[slot] = x._h
+        return handles, n_slots, keep
 
     def launches(self):
         p = self.program()
@@ -251,25 +282,23 @@ class SpecializedAst:
     def eval_batch(self, inputs=(), batch=1, out=None):
         """One evaluation per batch item.  inputs[slot]: DeviceMV (batch items, or 1 = shared),
         a [batch, row_len] array, or None for unused slots.  Returns the output DeviceMV."""
-        L = _lib.lib()
         prog = self.program()
-        n_slots = L.gaast_spec_num_inputs(self._p)
-        desc = self.program_desc()
-        handles = (C.c_void_p * max(1, n_slots))()
-        keep = []
-        for slot in range(min(len(inputs), n_slots)):
-            x = inputs[slot]
-            if x is None:
-                continue
-            if not isinstance(x, DeviceMV):
-                ind = desc.inputs[slot]
-                x = DeviceMV.from_rows(ind.storage_dim, GradeSet(ind.grade_mask), x, self.dtype)
-            keep.append(x)
-            handles[slot] = x._h
-        mask, _ = self.output_info()
+        handles, n_slots, keep = self._bind(inputs)
         if out is None:
+            mask, _ = self.output_info()
             out = DeviceMV.alloc(self.get_node(self.root_id()).vec_space_dim, GradeSet(mask), batch, self.dtype)
-        _lib.check(L.gaast_hip_eval(prog, handles, n_slots, batch, out._h))
+        _lib.check(_lib.lib().gaast_hip_eval(prog, handles, n_slots, batch, out._h))
+        out._keep_inputs = keep
+        return out
+
+    def eval_gather(self, inputs, out, gathered, counts, root=0, n_chunks=4):
+        """gaast_hip_eval_gather: evaluate this rank's shard (counts[rank] items) in n_chunks chunks, chunk k travelling
+        to `root` over RCCL while chunk k + 1 is computed.  `gathered` (root only) receives all ranks' rows in item order."""
+        prog = self.program()
+        handles, n_slots, keep = self._bind(inputs)
+        cnt = (C.c_int64 * len(counts))(*counts)
+        _lib.check(_lib.lib().gaast_hip_eval_gather(prog, handles, n_slots, out._h, gathered._h if gathered is not None else None,
+                                                    cnt, root, n_chunks))
         out._keep_inputs = keep
         return out
 

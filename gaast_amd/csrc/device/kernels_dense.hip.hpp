@@ -13,9 +13,14 @@ namespace gaast {
 //     s(a,b) = s_hi(a_hi,b_hi) * s_lo(a_lo,b_lo) * (-1)^(|a_hi| |b_lo|)
 // so an aligned 16-block of A times an aligned 16-block of B lands in exactly one 16-block
 // of C, with a compile-time sign pattern (two variants, by the parity of |a_hi|) and one
-// run-time sign per (a_hi, b_hi).  The lo four basis vectors must square to +1; the
-// metric of the others (+1/-1/0) is folded into the per-block sign / zero factor:
+// run-time sign per (a_hi, b_hi).  The metric of the hi basis vectors (+1/-1/0) is folded into the
+// per-block sign / zero factor:
 //     (-1)^|a_hi & b_hi & NEG|  and  [a_hi & b_hi & ZERO == 0].
+// The lo basis vectors must square to +-1 (never 0): their factor (-1)^|a_lo & b_lo & NEG_lo| is a lane
+// constant in the matrix-core kernels (any NEG_lo) and a compile-time pattern in the vector-FMA kernel
+// (NEG_lo = none or all four).  The host gets any diagonal metric into that shape by PERMUTING the basis
+// vectors (plan.cpp: dense_basis_permutation): the kernels work on blades of the permuted basis, the index maps
+// carry the blade bijection and the reordering sign of every blade in their negate bits.
 //
 // Mapping: lane <-> c_hi (one 16-component block of the result in 16 accumulators),
 // 2^(n-4) lanes per item.  Both operands of the item sit in LDS in bitmask order (scattered
@@ -38,10 +43,11 @@ struct DenseArgs {
     int left_count, right_count;
     int left_full, right_full;  // 1: every blade is loaded, no zero fill needed
     int left_contig, right_contig;  // 1: row offsets are 0,1,2,... and rows are 16-byte aligned: vector loads
-    const int32_t* out_map;     // per bitmask: offset in the out row, or -1
+    const int32_t* out_map;     // per bitmask: offset in the out row [29:0] | negate << 30, or -1
     int canon_left, canon_right;
     int n;                      // vector-space dimension, 4 <= n
     uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
+    uint32_t neg_lo;            // lo basis vectors that square to -1
     int beta;
     int64_t batch;
 };
@@ -133,6 +139,16 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
     }
 }
 
+// result component -> graded row: out_map word = offset | negate << 30 (the blade's reordering sign under the basis
+// permutation), -1 = not produced
+template <typename T>
+__device__ __forceinline__ void store_result(T* __restrict__ orow, int32_t w, T v, int beta) {
+    if (w < 0) return;
+    const int32_t off = w & 0x3fffffff;
+    if (w & 0x40000000) v = -v;
+    orow[off] = beta ? orow[off] + v : v;
+}
+
 __device__ __forceinline__ constexpr int lo_reorder_parity(int a, int b) {
     // parity of #{(p,q): p in a, q in b, p > q} for 4-bit a, b
     int par = 0;
@@ -150,13 +166,14 @@ template <>
 __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ---- 16x16 block product, generic (used for f64): 256 scalar FMAs with folded signs ----------
-template <typename T, bool ODD>
+template <typename T, bool ODD, bool NEGLO>
 __device__ __forceinline__ void gp_block16(const T (&A)[16], const T (&B)[16], T (&C)[16]) {
 #pragma unroll
     for (int al = 0; al < 16; ++al) {
 #pragma unroll
         for (int bl = 0; bl < 16; ++bl) {
-            const int neg = lo_reorder_parity(al, bl) ^ (ODD ? (__builtin_popcount(bl) & 1) : 0);
+            const int neg = lo_reorder_parity(al, bl) ^ (ODD ? (__builtin_popcount(bl) & 1) : 0) ^
+                            (NEGLO ? (__builtin_popcount(al & bl) & 1) : 0);
             C[al ^ bl] = neg ? fma_t<T>(-A[al], B[bl], C[al ^ bl]) : fma_t<T>(A[al], B[bl], C[al ^ bl]);
         }
     }
@@ -188,15 +205,17 @@ __device__ __forceinline__ void pk_fma_sel(float2v& c, const float2v& a, const f
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(c) : "v"(a), "v"(b));
 }
 
-template <bool ODD, int IDX>
+template <bool ODD, bool NEGLO, int IDX>
 __device__ __forceinline__ void gp_block16_pk(const float2v (&A2)[8], const float2v (&B2)[8], float2v (&C2)[8]) {
     if constexpr (IDX < 128) {
         constexpr int a = IDX >> 3, j = IDX & 7, c0 = 2 * j;
         constexpr int b_lo = a ^ c0, b_hi = a ^ c0 ^ 1;
-        constexpr int nl = lo_reorder_parity(a, b_lo) ^ (ODD ? (__builtin_popcount(b_lo) & 1) : 0);
-        constexpr int nh = lo_reorder_parity(a, b_hi) ^ (ODD ? (__builtin_popcount(b_hi) & 1) : 0);
+        constexpr int nl = lo_reorder_parity(a, b_lo) ^ (ODD ? (__builtin_popcount(b_lo) & 1) : 0) ^
+                           (NEGLO ? (__builtin_popcount(a & b_lo) & 1) : 0);
+        constexpr int nh = lo_reorder_parity(a, b_hi) ^ (ODD ? (__builtin_popcount(b_hi) & 1) : 0) ^
+                           (NEGLO ? (__builtin_popcount(a & b_hi) & 1) : 0);
         pk_fma_sel<(a & 1), nl, nh>(C2[j], A2[a >> 1], B2[b_lo >> 1]);
-        gp_block16_pk<ODD, IDX + 1>(A2, B2, C2);
+        gp_block16_pk<ODD, NEGLO, IDX + 1>(A2, B2, C2);
     }
 }
 
@@ -211,7 +230,7 @@ struct BlockStep<float> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) C2[i] = float2v{0.f, 0.f};
     }
-    template <bool ODD>
+    template <bool ODD, bool NEGLO>
     __device__ __forceinline__ void step(const float* As, const float* Bs, int a_hi, int b_hi, float sgn) {
         const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
         const float4v* ap = reinterpret_cast<const float4v*>(As + (a_hi << 4));
@@ -227,7 +246,7 @@ struct BlockStep<float> {
             B2[2 * q] = float2v{vb.x, vb.y} * s2;
             B2[2 * q + 1] = float2v{vb.z, vb.w} * s2;
         }
-        gp_block16_pk<ODD, 0>(A2, B2, C2);
+        gp_block16_pk<ODD, NEGLO, 0>(A2, B2, C2);
     }
     __device__ __forceinline__ float get(int i) const { return (i & 1) ? C2[i >> 1].y : C2[i >> 1].x; }
 };
@@ -239,7 +258,7 @@ struct BlockStep<double> {
 #pragma unroll
         for (int i = 0; i < 16; ++i) C[i] = 0.0;
     }
-    template <bool ODD>
+    template <bool ODD, bool NEGLO>
     __device__ __forceinline__ void step(const double* As, const double* Bs, int a_hi, int b_hi, double sgn) {
         const int sa = (a_hi >> 2) & 3, sb = (b_hi >> 2) & 3;
         // a "quad" is 4 components = two 16-byte halves for f64
@@ -253,12 +272,13 @@ struct BlockStep<double> {
             A[4 * q + 0] = a0.x; A[4 * q + 1] = a0.y; A[4 * q + 2] = a1.x; A[4 * q + 3] = a1.y;
             B[4 * q + 0] = b0.x * sgn; B[4 * q + 1] = b0.y * sgn; B[4 * q + 2] = b1.x * sgn; B[4 * q + 3] = b1.y * sgn;
         }
-        gp_block16<double, ODD>(A, B, C);
+        gp_block16<double, ODD, NEGLO>(A, B, C);
     }
     __device__ __forceinline__ double get(int i) const { return C[i]; }
 };
 
-template <typename T, bool DEGENERATE, int THREADS>
+// NEGLO: all four lo basis vectors square to -1 (else: all four to +1)
+template <typename T, bool DEGENERATE, int THREADS, bool NEGLO>
 __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
                 if (DEGENERATE) {
                     if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) sgn = zero;
                 }
-                acc.template step<ODD>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
+                acc.template step<ODD, NEGLO>(As, Bs, a_hi, a_hi ^ c_hi, sgn);
             };
             const int half = LPI >> 1;
             for (int i = 0; i < half; ++i) one_step(std::false_type{}, (i << 1) | (__builtin_popcount(uint32_t(i)) & 1));
@@ -330,10 +350,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
             // ---- scatter the 16 accumulators to their positions in the graded row ----
             T* orow = p.out + (item0 + it) * p.out_stride;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int32_t off = om[i];
-                if (off >= 0) orow[off] = p.beta ? orow[off] + acc.get(i) : acc.get(i);
-            }
+            for (int i = 0; i < 16; ++i) store_result<T>(orow, om[i], acc.get(i), p.beta);
         }
         __syncthreads();  // the LDS image is rewritten by the next group
     }
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
 // quads rotated by (x>>1)&7 per block x: 16 lanes reading the same logical quad of 16 blocks
 // hit 16 different bank quads), times the block sign.  f32 MFMA accumulates like a k-ordered
 // fmaf chain, at the vector FMA rate, without occupying the vector ALUs.
-// Requires the low FIVE basis vectors to square to +1.
+// The low FIVE basis vectors square to +-1 (p.neg_lo; the host permutes the basis to make it so).
 // ------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ constexpr int lo5_reorder_parity(int a, int b) {
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int s2 = 0; s2 < 16; ++s2) {
             const int k = 2 * s2 + h;
             const int a_lo = i ^ k;
-            int par = 0;
+            int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
             for (int pp = 1; pp < 5; ++pp)
                 if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
             amask[s2] = uint32_t(par) << 31;
@@ -481,8 +498,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int32_t off = om[c_lo];
-            if (off >= 0) orow[off] = p.beta ? orow[off] + acc[r] : acc[r];
+            store_result<float>(orow, om[c_lo], acc[r], p.beta);
         }
     }
 }
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int a_lo = i ^ k;
-        int par = 0;
+        int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
         amask[k] = uint32_t(par) << 31;
@@ -598,10 +614,7 @@ __global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
         if (item < nitems) {
             float* orow = p.out + (item0 + item) * p.out_stride;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int32_t off = om[4 * rg + r];
-                if (off >= 0) orow[off] = p.beta ? orow[off] + acc[4 * b + r] : acc[4 * b + r];
-            }
+            for (int r = 0; r < 4; ++r) store_result<float>(orow, om[4 * rg + r], acc[4 * b + r], p.beta);
         }
     }
 }

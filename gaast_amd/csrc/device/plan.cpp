@@ -15,6 +15,7 @@
 #include "plan.hpp"
 #include "spinor_basis.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -264,19 +265,55 @@ struct Lowering {
         return same;
     }
 
-    bool dense_eligible(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r) const {
-        if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
-        if (!is_geometric_list(nd)) return false;
+    // Basis permutation that brings a diagonal metric into the shape the dense kernels want: position j of the
+    // permuted basis holds original vector perm[j]; positions [0, L) (the "lo" bits of a blade) hold vectors that
+    // square to +-1 (+1 first), never 0.  uniform: the four lo vectors must all square to the same sign (vector-FMA
+    // kernel: compile-time sign pattern).  The identity is kept whenever it already qualifies.
+    bool dense_basis_permutation(int L, bool uniform, std::vector<int>& perm) const {
         const int n = d.vec_space_dim;
-        if (n < 6 || n > 13) return false;  // small algebras: the exact kernel is HBM-bound anyway
-        if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return false;
+        std::vector<int> plus, minus;
+        for (int i = 0; i < n; ++i) {
+            if (d.metric_diag[i] == 1.0) plus.push_back(i);
+            if (d.metric_diag[i] == -1.0) minus.push_back(i);
+        }
+        std::vector<int> lo;
+        if (uniform) {
+            if (int(plus.size()) >= L) lo.assign(plus.begin(), plus.begin() + L);
+            else if (int(minus.size()) >= L) lo.assign(minus.begin(), minus.begin() + L);
+            else return false;
+        } else {
+            if (int(plus.size() + minus.size()) < L) return false;
+            for (int i : plus) if (int(lo.size()) < L) lo.push_back(i);
+            for (int i : minus) if (int(lo.size()) < L) lo.push_back(i);
+        }
+        std::sort(lo.begin(), lo.end());
+        std::vector<char> is_lo(size_t(n), 0);
+        for (int i : lo) is_lo[size_t(i)] = 1;
+        perm = lo;
+        for (int i = 0; i < n; ++i)
+            if (!is_lo[size_t(i)]) perm.push_back(i);
+        return true;
+    }
+
+    // which dense kernel (0 = none, 1 = k_gp_dense, 2 = k_gp_mfma16, 3 = k_gp_mfma32) and in which basis
+    int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
+        if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
+        const int n = d.vec_space_dim;
+        if (n < 6 || n > 13) return 0;  // small algebras: the exact kernel is HBM-bound anyway
+        if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return 0;
         for (int i = 0; i < n; ++i) {
             const double g = d.metric_diag[i];
-            if (g != 1.0 && g != -1.0 && g != 0.0) return false;
-            if (i < 4 && g != 1.0) return false;
+            if (g != 1.0 && g != -1.0 && g != 0.0) return 0;
         }
         const double full = double(uint64_t(1) << (2 * n));
-        return double(nd.n_comp_muls) * 8.0 >= full;  // the tiled kernel always does 4^n multiply-adds
+        if (double(nd.n_comp_muls) * 8.0 < full) return 0;  // the tiled kernels always do 4^n multiply-adds
+        if (!is_geometric_list(nd)) return 0;
+        const bool mfma_ok = plan.dtype == GAAST_F32 && !(plan.flags & GAAST_FLAG_NO_MFMA);
+        // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (four items per wave)
+        if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
+        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
+        if (dense_basis_permutation(4, true, perm)) return 1;
+        return 0;
     }
 
     // opt-in matrix-representation kernels: f32, n = 7..12 (odd n as the subalgebra of n + 1), every
@@ -400,7 +437,8 @@ struct Lowering {
                 return;
             }
         }
-        if (dense_eligible(nd, res, l, r)) {
+        std::vector<int> perm;
+        if (const int dense_kind = dense_choice(nd, res, l, r, perm)) {
             if ((omin & lr.mask) != omin) {
                 fail(GAAST_ERR_MISSING_GRADE, "product result grade absent from result buffer");
                 return;
@@ -417,11 +455,28 @@ struct Lowering {
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
             const int n = d.vec_space_dim;
-            // matrix-core variant: f32, n >= 10 (32 result columns per wave), low FIVE vectors +1
-            s.use_mfma = plan.dtype == GAAST_F32 && n >= 10 && n <= 13 && d.metric_diag[4] == 1.0 &&
-                         !(plan.flags & GAAST_FLAG_NO_MFMA);
-            // 16 x 16 four-block matrix-core variant: f32, n = 8, 9 (four items per wave)
-            s.use_mfma16 = plan.dtype == GAAST_F32 && (n == 8 || n == 9) && !(plan.flags & GAAST_FLAG_NO_MFMA);
+            s.use_mfma = dense_kind == 3;
+            s.use_mfma16 = dense_kind == 2;
+            // blade S of the program's basis <-> blade S' of the permuted basis, e_S = sign(S) e'_S' (the parity of the
+            // inversions of the new positions of S's vectors taken in ascending original order)
+            std::vector<int> inv(size_t(n), 0);
+            bool identity = true;
+            for (int j = 0; j < n; ++j) {
+                inv[size_t(perm[size_t(j)])] = j;
+                identity = identity && perm[size_t(j)] == j;
+            }
+            std::vector<uint32_t> new_blade(size_t(1) << n), blade_sign(size_t(1) << n);
+            for (uint32_t S = 0; S < (1u << n); ++S) {
+                uint32_t S2 = 0, par = 0;
+                for (int p = 0; p < n; ++p) {
+                    if (!((S >> p) & 1u)) continue;
+                    const int q = inv[size_t(p)];
+                    par ^= uint32_t(__builtin_popcount(S2 >> (q + 1))) & 1u;
+                    S2 |= 1u << q;
+                }
+                new_blade[S] = S2;
+                blade_sign[S] = par;
+            }
             // position of blade m in the LDS image the kernel reads (mirrors kernels.hip.hpp)
             auto vec_pos = [](uint32_t m) {  // dense_lds_pos
                 const uint32_t x = m >> 4, lo = m & 15;
@@ -438,9 +493,10 @@ struct Lowering {
                 bool seq = true;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
-                    const uint32_t sgn = ((flip >> k) & 1ULL) ? 0x80000000u : 0u;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
-                        const uint32_t blade = bt.blade_of[size_t(k)][i];
+                        const uint32_t orig = bt.blade_of[size_t(k)][i];
+                        const uint32_t blade = new_blade[orig];
+                        const uint32_t sgn = (uint32_t((flip >> k) & 1ULL) ^ blade_sign[orig]) ? 0x80000000u : 0u;
                         const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
                                              : s.use_mfma16 ? (right ? vec_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
@@ -453,18 +509,27 @@ struct Lowering {
             };
             build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full, &s.left_contig);
             build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full, &s.right_contig);
+            // out_map: indexed by the blade of the permuted basis; offset | reordering sign << 30, or -1
             s.i32_a.assign(size_t(1) << n, -1);
             for (uint32_t m = 0; m < (1u << n); ++m) {
                 const int g = __builtin_popcount(m);
-                if ((omin >> g) & 1ULL) s.i32_a[m] = int32_t(lr.offset(g) + bt.index_of[m]);
+                if ((omin >> g) & 1ULL)
+                    s.i32_a[new_blade[m]] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (blade_sign[m] << 30));
             }
             const int lo_bits = s.use_mfma ? 5 : 4;
-            for (int i = lo_bits; i < n; ++i) {
-                if (d.metric_diag[i] == -1.0) s.neg_hi |= 1u << (i - lo_bits);
-                if (d.metric_diag[i] == 0.0) s.zero_hi |= 1u << (i - lo_bits);
+            for (int j = 0; j < n; ++j) {
+                const double g = d.metric_diag[perm[size_t(j)]];
+                if (j < lo_bits) {
+                    if (g == -1.0) s.neg_lo |= 1u << j;
+                } else {
+                    if (g == -1.0) s.neg_hi |= 1u << (j - lo_bits);
+                    if (g == 0.0) s.zero_hi |= 1u << (j - lo_bits);
+                }
             }
+            s.neg_lo_all = dense_kind == 1 && s.neg_lo == 15u;
             s.degenerate = s.zero_hi != 0;
-            if (s.use_mfma || s.use_mfma16) s.name = "product_dense_mfma[gp n=" + std::to_string(n) + "]";
+            s.name = std::string(dense_kind == 1 ? "product_dense" : "product_dense_mfma") + "[gp n=" + std::to_string(n) +
+                     (identity ? "" : " permuted basis") + "]";
             touch(res);
             return;
         }

@@ -53,6 +53,8 @@ struct Step {
     int left_full = 0, right_full = 0, out_full = 0;
     int left_contig = 0, right_contig = 0;
     uint32_t neg_hi = 0, zero_hi = 0;
+    uint32_t neg_lo = 0;   // lo basis vectors (of the permuted basis) that square to -1
+    int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)
     int degenerate = 0;
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16 (f32, n = 8, 9)
@@ -69,6 +71,14 @@ struct Step {
     std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
     void* jit_module = nullptr;
     void* jit_function = nullptr;
+    // launch configuration, fixed once at gaast_hip_program_create (runtime.hip: prepare_step): kernel, block
+    // size, dynamic LDS, persistent-grid size.  ELL products pick kern[log2(items per pass)] by batch.
+    const void* kern[4] = {nullptr, nullptr, nullptr, nullptr};
+    int threads = 0;
+    size_t lds = 0;            // bytes per launch (ELL / CSR: per staged item)
+    int max_items = 0;         // ELL / CSR: items per workgroup when the batch allows
+    int items_per_block = 0;   // dense kernels
+    int blocks_per_cu = 0;     // persistent kernels: resident workgroups per CU
     // device copies
     void* d_a = nullptr;
     void* d_b = nullptr;
@@ -90,6 +100,8 @@ struct Plan {
     std::vector<Step> steps;
     int error = GAAST_OK;              // what the reference would have panicked with, at eval
     std::string error_msg;
+    std::vector<char> slot_used;       // input slots some launch reads (the others may stay unbound)
+    std::string jit_source_kept;       // GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE
 };
 
 // Throws std::runtime_error (-> GAAST_ERR_INVALID_PROGRAM) on malformed input.

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -12,6 +13,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "comm.hpp"
 #include "gaast_hip.h"
 #include "kernels.hip.hpp"
 #include "plan.hpp"
@@ -29,6 +31,9 @@ int g_device = -1;
 hipStream_t g_stream = nullptr;
 int g_num_cu = 256;
 size_t g_max_lds = 160 * 1024;
+Comm g_comm;                       // the gather communicator (gaast_hip_comm_init), if any
+std::vector<hipEvent_t> g_events;  // chunk-done events of gaast_hip_eval_gather, created on demand
+hipEvent_t g_comm_done = nullptr;
 
 int set_err(int status, const std::string& msg) {
     g_err = msg;
@@ -42,9 +47,12 @@ int set_err(int status, const std::string& msg) {
             return set_err(GAAST_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// Every entry point that touches the GPU starts here: HIP's current device is per host thread, the library's
+// device is per process (include/gaast_hip.h, conventions).
 int ensure_init() {
-    if (g_init) return GAAST_OK;
-    return set_err(GAAST_ERR_NO_DEVICE, "gaast_hip_init() has not been called (or found no GPU)");
+    if (!g_init) return set_err(GAAST_ERR_NO_DEVICE, "gaast_hip_init() has not been called (or found no GPU)");
+    HIP_TRY(hipSetDevice(g_device));
+    return GAAST_OK;
 }
 
 size_t dtype_size(int dtype) { return dtype == GAAST_F32 ? 4 : 8; }
@@ -60,15 +68,43 @@ struct gaast_hip_mv_s {
     bool owns = false;
 };
 
+struct gaast_hip_program_s;
+
+namespace {
+void mv_free_impl(gaast_hip_mv_t m);
+void release_plan_resources(Plan& plan);
+}  // namespace
+
 struct gaast_hip_program_s {
     Plan plan;
     std::vector<gaast_hip_mv_t> const_mvs;  // per input slot (nullptr for bound slots)
     std::vector<gaast_hip_mv_t> scratch;    // per node buffer, sized for scratch_batch
     int64_t scratch_batch = 0;
     std::vector<std::string> launch_names;
+    gaast_hip_program_s() = default;
+    gaast_hip_program_s(const gaast_hip_program_s&) = delete;
+    gaast_hip_program_s& operator=(const gaast_hip_program_s&) = delete;
+    ~gaast_hip_program_s() {  // every failure path of program_create and program_destroy end here
+        release_plan_resources(plan);
+        for (gaast_hip_mv_t m : const_mvs) mv_free_impl(m);
+        for (gaast_hip_mv_t m : scratch) mv_free_impl(m);
+    }
 };
 
 namespace {
+
+// device tables and hiprtc modules of a plan (also called before a plan is rebuilt)
+void release_plan_resources(Plan& plan) {
+    for (Step& s : plan.steps) {
+        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        if (s.jit_module) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module));
+        s.jit_module = nullptr;
+        s.jit_function = nullptr;
+    }
+}
 
 template <typename T>
 int upload_vec(const std::vector<T>& v, void** dptr) {
@@ -119,6 +155,127 @@ struct Bound {  // a buffer resolved for one eval call
     int64_t stride;
 };
 
+// kernels whose dynamic LDS exceeds the 64 KiB default need the attribute raised, once
+int allow_lds(const void* kern, size_t lds) {
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    return GAAST_OK;
+}
+
+int resident_blocks(const void* kern, int threads, size_t lds, int* per_cu) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, threads, lds));
+    if (*per_cu < 1) *per_cu = 1;
+    return GAAST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch configuration of one step, decided ONCE at gaast_hip_program_create: which kernel instantiation,
+// block size, dynamic LDS, persistent grid.  A step no kernel of this back end can run (operands beyond the LDS
+// budget) makes program_create fail with UNIMPLEMENTED: an eval then either runs every step or none.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
+    constexpr bool is_f64 = std::is_same<T, double>::value;
+    switch (s.kind) {
+    case Step::PRODUCT_CSR: {
+        const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
+        if (per_item > g_max_lds)
+            return set_err(GAAST_ERR_UNIMPLEMENTED,
+                           "product operands of " + std::to_string(per_item) + " bytes per item do not fit the " +
+                               std::to_string(g_max_lds) + "-byte LDS of the list kernels (" + s.name + ")");
+        s.lds = per_item;
+        s.threads = 256;
+        if (s.ell_width > 0) {
+            // items per pass over the list: as many as a 64 KiB share of LDS holds (at least one), at most 8
+            int items = int((64 * 1024) / per_item);
+            items = items >= 8 ? 8 : items >= 4 ? 4 : items >= 2 ? 2 : 1;
+            s.max_items = items;
+            using KernE = void (*)(EllArgs<T>);
+            const KernE tab[2][4] = {{&k_product_ell<T, 1, false>, &k_product_ell<T, 2, false>, &k_product_ell<T, 4, false>, &k_product_ell<T, 8, false>},
+                                     {&k_product_ell<T, 1, true>, &k_product_ell<T, 2, true>, &k_product_ell<T, 4, true>, &k_product_ell<T, 8, true>}};
+            for (int l2 = 0; (1 << l2) <= items; ++l2) {
+                s.kern[l2] = reinterpret_cast<const void*>(tab[s.ell_bytes ? 1 : 0][l2]);
+                if (int st = allow_lds(s.kern[l2], per_item << l2)) return st;
+            }
+            return GAAST_OK;
+        }
+        // enough items per block to give 256 threads work, within a 64 KiB LDS budget
+        const int n_rows = int(s.u32_b.size());
+        int items = int((256 + n_rows - 1) / (n_rows > 0 ? n_rows : 1));
+        const size_t budget = 64 * 1024;
+        if (per_item * size_t(items) > budget) items = int(budget / per_item);
+        if (items < 1) items = 1;
+        s.max_items = items;
+        s.kern[0] = reinterpret_cast<const void*>(&k_product_csr<T>);
+        return allow_lds(s.kern[0], per_item * size_t(items));
+    }
+    case Step::PRODUCT_DENSE: {
+        if (s.use_spinor) {
+            using KernS = void (*)(SpinorArgs);
+            const int m = s.use_spinor;
+            if (is_f64 && m != 6)
+                return set_err(GAAST_ERR_UNIMPLEMENTED, "f64 matrix-representation product exists for n = 11, 12 only");
+            const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
+            s.lds = (m == 6 ? 2 * plane : 2 * D * (D + 1)) * sizeof(T);
+            const int lb5 = s.spinor_lam_bit;
+            KernS kern = nullptr;
+            if (is_f64) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
+            else if (m == 6) kern = lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>;
+            else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
+            else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;
+            s.kern[0] = reinterpret_cast<const void*>(kern);
+            s.threads = m == 6 ? 256 : 64;
+            if (int st = allow_lds(s.kern[0], s.lds)) return st;
+            return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
+        }
+        if (s.use_mfma) {
+            if constexpr (!is_f64) {
+                const int wpi = 1 << (n - 10);                 // waves per item
+                s.threads = wpi > 4 ? wpi * 64 : 256;
+                s.items_per_block = (s.threads / 64) / wpi;
+                s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
+                if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
+                auto kern = s.threads == 256 ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
+                                             : (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>);
+                s.kern[0] = reinterpret_cast<const void*>(kern);
+                return allow_lds(s.kern[0], s.lds);
+            }
+        }
+        if (s.use_mfma16) {
+            if constexpr (!is_f64) {
+                const int wpg = 1 << (n - 8);                  // waves per group of four items
+                s.threads = 256;
+                s.items_per_block = 4 * (4 / wpg);
+                s.lds = size_t(s.items_per_block) * size_t((2 << n) + 16) * sizeof(float);
+                auto kern = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8> : &k_gp_mfma16<false, 8>)
+                                   : (s.degenerate ? &k_gp_mfma16<true, 9> : &k_gp_mfma16<false, 9>);
+                s.kern[0] = reinterpret_cast<const void*>(kern);
+                return allow_lds(s.kern[0], s.lds);
+            }
+        }
+        const int lpi = 1 << (n - 4);
+        s.threads = lpi > 256 ? lpi : 256;
+        s.items_per_block = s.threads / lpi;
+        s.lds = size_t(s.items_per_block) * size_t(2 * (1 << n) + (s.items_per_block > 1 ? 4 : 0)) * sizeof(T);
+        if (s.lds > g_max_lds)
+            return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product of dimension " + std::to_string(n) + " does not fit in LDS");
+        using KernD = void (*)(DenseArgs<T>);
+        KernD kern;
+        if (s.neg_lo_all)
+            kern = s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, true> : &k_gp_dense<T, false, 256, true>)
+                                    : (s.degenerate ? &k_gp_dense<T, true, 512, true> : &k_gp_dense<T, false, 512, true>);
+        else
+            kern = s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false> : &k_gp_dense<T, false, 256, false>)
+                                    : (s.degenerate ? &k_gp_dense<T, true, 512, false> : &k_gp_dense<T, false, 512, false>);
+        s.kern[0] = reinterpret_cast<const void*>(kern);
+        if (int st = allow_lds(s.kern[0], s.lds)) return st;
+        // persistent workgroups: as many as are resident at once (register- and LDS-limited)
+        return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
+    }
+    default: return GAAST_OK;
+    }
+}
+
 template <typename T>
 int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, const Layout& la,
              const Layout& lb, int64_t batch, int n) {
@@ -160,22 +317,12 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             q.width = s.ell_width;
             q.beta = s.beta;
             q.batch = batch;
-            const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
-            if (per_item > g_max_lds)
-                return set_err(GAAST_ERR_INVALID_PROGRAM, "product operands do not fit in LDS (exact kernel)");
-            // items per pass over the list: as many as a 64 KiB share of LDS holds (at least one), at most 8
-            int items = int((64 * 1024) / per_item);
-            items = items >= 8 ? 8 : items >= 4 ? 4 : items >= 2 ? 2 : 1;
-            while (items > 1 && int64_t(items) > batch) items >>= 1;
+            int l2 = s.max_items >= 8 ? 3 : s.max_items >= 4 ? 2 : s.max_items >= 2 ? 1 : 0;
+            while (l2 > 0 && (int64_t(1) << l2) > batch) --l2;
             using KernE = void (*)(EllArgs<T>);
-            KernE kern = s.ell_bytes ? (items == 8 ? &k_product_ell<T, 8, true> : items == 4 ? &k_product_ell<T, 4, true> : items == 2 ? &k_product_ell<T, 2, true> : &k_product_ell<T, 1, true>)
-                                     : (items == 8 ? &k_product_ell<T, 8, false> : items == 4 ? &k_product_ell<T, 4, false> : items == 2 ? &k_product_ell<T, 2, false> : &k_product_ell<T, 1, false>);
-            const size_t lds = per_item * size_t(items);
-            if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            const int64_t blocks = (batch + items - 1) / items;
-            hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(256), lds, g_stream, q);
+            const int64_t blocks = (batch + (int64_t(1) << l2) - 1) >> l2;
+            hipLaunchKernelGGL(reinterpret_cast<KernE>(const_cast<void*>(s.kern[l2])), dim3(unsigned(blocks)), dim3(256),
+                               s.lds << l2, g_stream, q);
             break;
         }
         CsrArgs<T> p;
@@ -196,28 +343,16 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.n_rows = int(s.u32_b.size());
         p.beta = s.beta;
         p.batch = batch;
-        const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
-        if (per_item > g_max_lds)
-            return set_err(GAAST_ERR_INVALID_PROGRAM, "product operands do not fit in LDS (exact kernel)");
-        // enough items per block to give 256 threads work, within a 64 KiB LDS budget
-        int items = int((256 + p.n_rows - 1) / (p.n_rows > 0 ? p.n_rows : 1));
-        const size_t budget = 64 * 1024;
-        if (per_item * size_t(items) > budget) items = int(budget / per_item);
-        if (items < 1) items = 1;
+        int items = s.max_items;
         if (int64_t(items) > batch) items = int(batch);
         p.items = items;
-        const size_t lds = per_item * size_t(items);
         const int64_t blocks = (batch + items - 1) / items;
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_product_csr<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_product_csr<T>, dim3(unsigned(blocks)), dim3(256), lds, g_stream, p);
+        hipLaunchKernelGGL(k_product_csr<T>, dim3(unsigned(blocks)), dim3(256), s.lds * size_t(items), g_stream, p);
         break;
     }
     case Step::FUSED: return GAAST_OK;  // launched by run_fused (needs every bound buffer)
     case Step::PRODUCT_DENSE: {
         if (s.use_spinor) {
-            constexpr bool is_f64 = std::is_same<T, double>::value;
             SpinorArgs q;
             q.left = a.ptr;
             q.right = b.ptr;
@@ -239,27 +374,10 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             q.batch = batch;
             q.has_alpha = s.spinor_has_alpha;
             using KernS = void (*)(SpinorArgs);
-            const int m = s.use_spinor;
-            if (is_f64 && m != 6)
-                return set_err(GAAST_ERR_INVALID_PROGRAM, "f64 matrix-representation product exists for n = 11, 12 only");
-            const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
-            const size_t lds = (m == 6 ? 2 * plane : 2 * D * (D + 1)) * sizeof(T);
-            const int lb5 = s.spinor_lam_bit;
-            KernS kern = nullptr;
-            if (is_f64) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
-            else if (m == 6) kern = lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>;
-            else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
-            else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;
-            const int threads = m == 6 ? 256 : 64;
-            if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
-            if (per_cu < 1) per_cu = 1;
-            int64_t blocks = int64_t(g_num_cu) * per_cu;
+            int64_t blocks = int64_t(g_num_cu) * s.blocks_per_cu;
             if (blocks > batch) blocks = batch;
-            hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, q);
+            hipLaunchKernelGGL(reinterpret_cast<KernS>(const_cast<void*>(s.kern[0])), dim3(unsigned(blocks)),
+                               dim3(unsigned(s.threads)), s.lds, g_stream, q);
             break;
         }
         DenseArgs<T> p;
@@ -287,55 +405,18 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.n = n;
         p.neg_hi = s.neg_hi;
         p.zero_hi = s.zero_hi;
+        p.neg_lo = s.neg_lo;
         p.beta = s.beta;
         p.batch = batch;
-        if (s.use_mfma) {
-            if constexpr (std::is_same<T, float>::value) {
-                const int wpi = 1 << (n - 10);                 // waves per item
-                const int threads = wpi > 4 ? wpi * 64 : 256;
-                const int ipb = (threads / 64) / wpi;
-                const size_t lds = size_t(ipb) * size_t(2 << n) * sizeof(float);
-                if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
-                auto kern = threads == 256 ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
-                                           : (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>);
-                if (lds > 64 * 1024)
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-                const int64_t blocks = (batch + ipb - 1) / ipb;
-                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
-                break;
-            }
+        using KernD = void (*)(DenseArgs<T>);
+        const int64_t groups = (batch + s.items_per_block - 1) / s.items_per_block;
+        int64_t blocks = groups;
+        if (s.blocks_per_cu > 0) {  // persistent workgroups (vector-FMA form)
+            blocks = int64_t(g_num_cu) * s.blocks_per_cu;
+            if (blocks > groups) blocks = groups;
         }
-        if (s.use_mfma16) {
-            if constexpr (std::is_same<T, float>::value) {
-                const int wpg = 1 << (n - 8);                  // waves per group of four items
-                const int ipb = 4 * (4 / wpg);
-                const size_t lds = size_t(ipb) * size_t((2 << n) + 16) * sizeof(float);
-                auto kern = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8> : &k_gp_mfma16<false, 8>)
-                                   : (s.degenerate ? &k_gp_mfma16<true, 9> : &k_gp_mfma16<false, 9>);
-                const int64_t blocks = (batch + ipb - 1) / ipb;
-                hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(256), lds, g_stream, p);
-                break;
-            }
-        }
-        const int lpi = 1 << (n - 4);
-        const int threads = lpi > 256 ? lpi : 256;
-        const int ipb = threads / lpi;
-        const size_t lds = size_t(ipb) * size_t(2 * (1 << n) + (ipb > 1 ? 4 : 0)) * sizeof(T);
-        if (lds > g_max_lds) return set_err(GAAST_ERR_INVALID_PROGRAM, "dense product does not fit in LDS");
-        const int64_t groups = (batch + ipb - 1) / ipb;
-        auto kern = threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256> : &k_gp_dense<T, false, 256>)
-                                   : (s.degenerate ? &k_gp_dense<T, true, 512> : &k_gp_dense<T, false, 512>);
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        // persistent workgroups: as many as are resident at once (register- and LDS-limited)
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
-        if (per_cu < 1) per_cu = 1;
-        int64_t blocks = int64_t(g_num_cu) * per_cu;
-        if (blocks > groups) blocks = groups;
-        hipLaunchKernelGGL(kern, dim3(unsigned(blocks)), dim3(threads), lds, g_stream, p);
+        hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[0])), dim3(unsigned(blocks)),
+                           dim3(unsigned(s.threads)), s.lds, g_stream, p);
         break;
     }
     }
@@ -440,7 +521,10 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
 extern "C" {
 
 const char* gaast_hip_last_error(void) { return g_err.c_str(); }
-const char* gaast_hip_version(void) { return "gaast-hip 0.1 (gfx950)"; }
+#ifndef GAAST_KERNELS_REV
+#define GAAST_KERNELS_REV "unknown"
+#endif
+const char* gaast_hip_version(void) { return "gaast-hip 0.2 (gfx950) kernels " GAAST_KERNELS_REV; }
 
 int gaast_hip_init(const int* device_ids, int n_dev) {
     if (n_dev != 1 || !device_ids)
@@ -464,6 +548,15 @@ int gaast_hip_init(const int* device_ids, int n_dev) {
 }
 
 int gaast_hip_shutdown(void) {
+    if (g_init) {
+        (void)hipSetDevice(g_device);
+        std::string err;
+        (void)comm_destroy(g_comm, &err);
+        for (hipEvent_t ev : g_events) (void)hipEventDestroy(ev);
+        g_events.clear();
+        if (g_comm_done) (void)hipEventDestroy(g_comm_done);
+        g_comm_done = nullptr;
+    }
     g_init = false;
     return GAAST_OK;
 }
@@ -476,13 +569,14 @@ int gaast_hip_set_stream(void* hip_stream) {
 int gaast_hip_synchronize(void) {
     if (int st = ensure_init()) return st;
     HIP_TRY(hipStreamSynchronize(g_stream));
+    if (g_comm.active()) HIP_TRY(hipStreamSynchronize(g_comm.stream));
     return GAAST_OK;
 }
 
 int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t* out) {
     if (!desc || !out) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
     if (int st = ensure_init()) return st;
-    auto prog = std::make_unique<gaast_hip_program_s>();
+    auto prog = std::make_unique<gaast_hip_program_s>();  // its destructor releases whatever a failure leaves behind
     try {
         build_plan(*desc, prog->plan);
     } catch (const std::exception& ex) {
@@ -494,14 +588,9 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         bool rebuild = false;
         for (Step& s : prog->plan.steps) {
             if (s.kind != Step::FUSED || s.jit_source.empty()) continue;
-            if (const char* dump = std::getenv("GAAST_DUMP_JIT")) {  // diagnostics: keep the generated source
-                if (FILE* fp = std::fopen(dump, "w")) {
-                    std::fputs(s.jit_source.c_str(), fp);
-                    std::fclose(fp);
-                }
-            }
+            if (desc->flags & GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE) prog->plan.jit_source_kept += s.jit_source;
             std::string log;
-            const bool ok = std::getenv("GAAST_TEST_HIPRTC_FAILS") ? false : jit_compile(s, &log);
+            const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, &log);
             if (ok)
                 s.name = "ast_jit" + s.name.substr(s.name.find('['));
             else if (!log.empty())
@@ -512,6 +601,7 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         if (!rebuild) break;
         gaast_program_desc d2 = *desc;
         d2.flags |= GAAST_FLAG_NO_JIT;
+        release_plan_resources(prog->plan);  // modules already loaded for other fused steps
         prog->plan = Plan();
         try {
             build_plan(d2, prog->plan);
@@ -520,7 +610,23 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         }
     }
     Plan& plan = prog->plan;
+    auto layout_of = [&](BufRef r) -> Layout {
+        if (r.idx < 0) return Layout();
+        switch (r.kind) {
+        case BufKind::NODE: return plan.node_buffers[size_t(r.idx)];
+        case BufKind::INPUT: return plan.input_layouts[size_t(r.idx)];
+        default: return plan.out_layout;
+        }
+    };
+    plan.slot_used.assign(plan.inputs.size(), 0);
     for (Step& s : plan.steps) {
+        // kernel choice, LDS budget, persistent grid: fixed here, and a program no kernel can run is refused whole
+        const Layout la = layout_of(s.a), lb = layout_of(s.b);
+        if (int st = plan.dtype == GAAST_F32 ? prepare_step<float>(s, la, lb, plan.n) : prepare_step<double>(s, la, lb, plan.n))
+            return st;
+        if (s.a.idx >= 0 && s.a.kind == BufKind::INPUT) plan.slot_used[size_t(s.a.idx)] = 1;
+        if (s.b.idx >= 0 && s.b.kind == BufKind::INPUT) plan.slot_used[size_t(s.b.idx)] = 1;
+        for (const Step::FusedInput& fi : s.fused_inputs) plan.slot_used[size_t(fi.slot)] = 1;
         if (int st = upload_vec(s.u32_a, &s.d_a)) return st;
         if (int st = upload_vec(s.u32_b, &s.d_b)) return st;
         if (int st = upload_vec(s.u32_c, &s.d_c)) return st;
@@ -562,15 +668,13 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
 
 int gaast_hip_program_destroy(gaast_hip_program_t prog) {
     if (!prog) return GAAST_OK;
-    for (Step& s : prog->plan.steps) {
-        for (void* p : {s.d_a, s.d_b, s.d_c, s.d_coeff, s.d_i32})
-            if (p) (void)hipFree(p);
-        if (s.jit_module) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module));
-    }
-    for (gaast_hip_mv_t m : prog->const_mvs) mv_free_impl(m);
-    for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
+    if (g_init) (void)hipSetDevice(g_device);
     delete prog;
     return GAAST_OK;
+}
+
+const char* gaast_hip_program_jit_source(gaast_hip_program_t prog) {
+    return prog ? prog->plan.jit_source_kept.c_str() : "";
 }
 
 int gaast_hip_program_output_info(gaast_hip_program_t prog, uint64_t* grade_mask, int64_t* row_len) {
@@ -603,6 +707,8 @@ int gaast_hip_mv_wrap(void* device_ptr, int dim, uint64_t grade_mask, int64_t ba
         delete m;
         return set_err(GAAST_ERR_INVALID_ARGUMENT, "row_stride shorter than the row");
     }
+    // a single row has no stride to speak of: keep the 2-D copies / memsets well-formed (pitch >= width)
+    if (batch <= 1 && row_stride < m->layout.row_len) row_stride = m->layout.row_len;
     m->batch = batch;
     m->dtype = dtype;
     m->row_stride = row_stride;
@@ -691,27 +797,24 @@ int gaast_hip_mv_zero(gaast_hip_mv_t mv) {
     return GAAST_OK;
 }
 
-int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inputs, int64_t batch,
-                   gaast_hip_mv_t out) {
+}  // extern "C"
+
+namespace {
+
+// argument checks of an eval + the (pointer, stride) of every bound input, for items [0, batch)
+int bind_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inputs, int64_t batch, gaast_hip_mv_t out,
+              std::vector<Bound>& in_bound) {
     if (!prog || !out || batch < 0) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
-    if (int st = ensure_init()) return st;
     Plan& plan = prog->plan;
     if (plan.error != GAAST_OK) return set_err(plan.error, plan.error_msg);  // the reference panics here
     if (n_inputs < 0 || (n_inputs && !inputs)) return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad inputs");
-
-    // bind inputs (GradedObj values)
-    std::vector<Bound> in_bound(plan.inputs.size(), Bound{nullptr, 0});
+    in_bound.assign(plan.inputs.size(), Bound{nullptr, 0});
     for (size_t i = 0; i < plan.inputs.size(); ++i) {
         gaast_hip_mv_t m = plan.inputs[i].is_const ? prog->const_mvs[i] : (int(i) < n_inputs ? inputs[i] : nullptr);
         const Layout& want = plan.input_layouts[i];
         if (!m) {
-            // slots no node refers to may stay unbound
-            bool used = false;
-            for (const Step& s : plan.steps)
-                used |= (s.a.kind == BufKind::INPUT && s.a.idx == int(i)) || (s.b.kind == BufKind::INPUT && s.b.idx == int(i));
-            for (const Step& s : plan.steps)
-                for (const Step::FusedInput& fi : s.fused_inputs) used |= fi.slot == int(i);
-            if (used) return set_err(GAAST_ERR_INVALID_ARGUMENT, "input slot " + std::to_string(i) + " is not bound");
+            // slots no launch reads may stay unbound
+            if (plan.slot_used[i]) return set_err(GAAST_ERR_INVALID_ARGUMENT, "input slot " + std::to_string(i) + " is not bound");
             continue;
         }
         if (m->layout.mask != want.mask || m->layout.dim != want.dim)
@@ -725,21 +828,35 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n
         return set_err(GAAST_ERR_INVALID_ARGUMENT, "output grade set / dimension differ from the root's");
     if (out->dtype != plan.dtype || out->batch != batch)
         return set_err(GAAST_ERR_INVALID_ARGUMENT, "output dtype / batch mismatch");
-    if (batch == 0) return GAAST_OK;
+    return GAAST_OK;
+}
+
+// the launches of one evaluation over items [first, first + count) of the bound buffers
+int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, gaast_hip_mv_t out, int64_t first, int64_t count) {
+    Plan& plan = prog->plan;
+    if (count == 0) return GAAST_OK;
+    const size_t sz = dtype_size(plan.dtype);
+    auto shifted = [&](Bound b) {
+        if (b.ptr && first) b.ptr = static_cast<char*>(b.ptr) + size_t(first) * size_t(b.stride) * sz;
+        return b;
+    };
+    std::vector<Bound> in_bound(in_bound0.size());
+    for (size_t i = 0; i < in_bound0.size(); ++i) in_bound[i] = shifted(in_bound0[i]);
+    const Bound out_b = shifted(Bound{out->ptr, out->row_stride});
 
     // cache buffers of the product operands (the per-eval HashMap<NodeId, R> of eval.rs:16)
-    if (prog->scratch_batch < batch || prog->scratch.size() != plan.node_buffers.size()) {
+    if (prog->scratch_batch < count || prog->scratch.size() != plan.node_buffers.size()) {
+        if (!prog->scratch.empty()) HIP_TRY(hipStreamSynchronize(g_stream));  // launches may still read the old ones
         for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
         prog->scratch.clear();
         for (const Layout& l : plan.node_buffers) {
             gaast_hip_mv_t m = nullptr;
-            if (int st = mv_alloc_impl(l.dim, l.mask, batch, plan.dtype, &m)) return st;
+            if (int st = mv_alloc_impl(l.dim, l.mask, count, plan.dtype, &m)) return st;
             prog->scratch.push_back(m);
         }
-        prog->scratch_batch = batch;
+        prog->scratch_batch = count;
     }
 
-    const size_t sz = dtype_size(plan.dtype);
     auto resolve = [&](BufRef r, Layout* lay) -> Bound {
         switch (r.kind) {
         case BufKind::NODE: {
@@ -748,32 +865,221 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n
             return Bound{m->ptr, m->row_stride};
         }
         case BufKind::INPUT: *lay = plan.input_layouts[size_t(r.idx)]; return in_bound[size_t(r.idx)];
-        default: *lay = out->layout; return Bound{out->ptr, out->row_stride};
+        default: *lay = out->layout; return out_b;
         }
     };
     for (const Step& s : plan.steps) {
         Layout lres, la, lb;
         const Bound res = resolve(s.res, &lres);
         if (s.kind == Step::FUSED) {
-            const int st = plan.dtype == GAAST_F32 ? run_fused<float>(s, plan, in_bound, res, batch)
-                                                   : run_fused<double>(s, plan, in_bound, res, batch);
+            const int st = plan.dtype == GAAST_F32 ? run_fused<float>(s, plan, in_bound, res, count)
+                                                   : run_fused<double>(s, plan, in_bound, res, count);
             if (st != GAAST_OK) return st;
             continue;
         }
         if (s.kind == Step::ZERO) {
             if (lres.row_len)
                 HIP_TRY(hipMemset2DAsync(res.ptr, size_t(res.stride) * sz, 0, size_t(lres.row_len) * sz,
-                                         size_t(batch), g_stream));
+                                         size_t(count), g_stream));
             continue;
         }
         Bound a{nullptr, 0}, b{nullptr, 0};
         if (s.a.idx >= 0) a = resolve(s.a, &la);
         if (s.b.idx >= 0) b = resolve(s.b, &lb);
-        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, batch, plan.n)
-                                               : run_step<double>(s, res, a, b, la, lb, batch, plan.n);
+        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, plan.n)
+                                               : run_step<double>(s, res, a, b, la, lb, count, plan.n);
         if (st != GAAST_OK) return st;
     }
     return GAAST_OK;
+}
+
+int rccl_err(const std::string& msg) { return set_err(GAAST_ERR_RCCL, msg); }
+
+// items [lo, hi) of chunk c when `count` items are cut into n_chunks contiguous chunks
+void chunk_span(int64_t count, int n_chunks, int c, int64_t* lo, int64_t* hi) {
+    const int64_t per = (count + n_chunks - 1) / n_chunks;
+    *lo = std::min<int64_t>(int64_t(c) * per, count);
+    *hi = std::min<int64_t>(*lo + per, count);
+}
+
+// chunk c of every rank's rows travels to root on the communicator's stream (the caller has made that stream
+// wait for the chunk's compute)
+int gather_chunk(gaast_hip_mv_t local, gaast_hip_mv_t gathered, const int64_t* counts, int root, int n_chunks, int c) {
+    std::string err;
+    const size_t sz = dtype_size(local->dtype);
+    const size_t row = size_t(local->layout.row_len);
+    if (g_comm.rank != root) {
+        int64_t lo, hi;
+        chunk_span(counts[g_comm.rank], n_chunks, c, &lo, &hi);
+        if (hi > lo && row)
+            if (comm_send(g_comm, static_cast<const char*>(local->ptr) + size_t(lo) * row * sz, size_t(hi - lo) * row, int(sz),
+                          root, &err))
+                return rccl_err(err);
+        return GAAST_OK;
+    }
+    // root: one receive per peer, grouped, so that the transfers of all xGMI links are in flight together
+    if (comm_group_start(&err)) return rccl_err(err);
+    int64_t first = 0;
+    int failed = 0;
+    for (int r = 0; r < g_comm.world; ++r) {
+        int64_t lo, hi;
+        chunk_span(counts[r], n_chunks, c, &lo, &hi);
+        if (r != root && hi > lo && row && !failed)
+            failed = comm_recv(g_comm, static_cast<char*>(gathered->ptr) + size_t(first + lo) * row * sz, size_t(hi - lo) * row,
+                               int(sz), r, &err);
+        first += counts[r];
+    }
+    std::string err2;
+    if (comm_group_end(&err2) && !failed) return rccl_err(err2);
+    if (failed) return rccl_err(err);
+    // the root's own rows: a device copy, unless `out` already is that part of `gathered`
+    int64_t lo, hi, first_root = 0;
+    for (int r = 0; r < root; ++r) first_root += counts[r];
+    chunk_span(counts[root], n_chunks, c, &lo, &hi);
+    char* dst = static_cast<char*>(gathered->ptr) + size_t(first_root + lo) * row * sz;
+    const char* src = static_cast<const char*>(local->ptr) + size_t(lo) * row * sz;
+    if (hi > lo && row && dst != src)
+        HIP_TRY(hipMemcpyAsync(dst, src, size_t(hi - lo) * row * sz, hipMemcpyDeviceToDevice, g_comm.stream));
+    return GAAST_OK;
+}
+
+int check_gather_args(gaast_hip_mv_t local, gaast_hip_mv_t gathered, const int64_t* counts, int root) {
+    if (!g_comm.active()) return rccl_err("no communicator: call gaast_hip_comm_init first");
+    if (!local || !counts || root < 0 || root >= g_comm.world) return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad gather argument");
+    int64_t total = 0;
+    for (int r = 0; r < g_comm.world; ++r) {
+        if (counts[r] < 0) return set_err(GAAST_ERR_INVALID_ARGUMENT, "negative row count");
+        total += counts[r];
+    }
+    if (counts[g_comm.rank] > local->batch) return set_err(GAAST_ERR_INVALID_ARGUMENT, "counts[rank] exceeds the local batch");
+    if (local->row_stride != local->layout.row_len && local->batch > 1)
+        return set_err(GAAST_ERR_INVALID_ARGUMENT, "gather needs contiguous rows (row_stride == row_len)");
+    if (g_comm.rank == root) {
+        if (!gathered) return set_err(GAAST_ERR_INVALID_ARGUMENT, "root needs a destination");
+        if (gathered->layout.mask != local->layout.mask || gathered->layout.dim != local->layout.dim || gathered->dtype != local->dtype)
+            return set_err(GAAST_ERR_INVALID_ARGUMENT, "gather destination: grade set / dimension / dtype differ");
+        if (gathered->batch < total) return set_err(GAAST_ERR_INVALID_ARGUMENT, "gather destination holds fewer rows than the ranks send");
+        if (gathered->row_stride != gathered->layout.row_len && gathered->batch > 1)
+            return set_err(GAAST_ERR_INVALID_ARGUMENT, "gather needs contiguous rows (row_stride == row_len)");
+    }
+    return GAAST_OK;
+}
+
+int chunk_event(int c, hipEvent_t* ev) {
+    while (int(g_events.size()) <= c) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g_events.push_back(e);
+    }
+    *ev = g_events[size_t(c)];
+    return GAAST_OK;
+}
+
+// after the last transfer: later work on the library stream (and gaast_hip_synchronize) sees the gathered rows
+int join_comm_stream() {
+    if (!g_comm_done) HIP_TRY(hipEventCreateWithFlags(&g_comm_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g_comm_done, g_comm.stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream, g_comm_done, 0));
+    return GAAST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inputs, int64_t batch,
+                   gaast_hip_mv_t out) {
+    if (int st = ensure_init()) return st;
+    std::vector<Bound> in_bound;
+    if (int st = bind_eval(prog, inputs, n_inputs, batch, out, in_bound)) return st;
+    return eval_range(prog, in_bound, out, 0, batch);
+}
+
+int gaast_hip_comm_unique_id(void* id_out) {
+    if (!id_out) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    std::string err;
+    if (comm_unique_id(id_out, &err)) return rccl_err(err);
+    return GAAST_OK;
+}
+
+int gaast_hip_comm_init(const void* id, int rank, int world) {
+    if (!id || world < 1 || rank < 0 || rank >= world) return set_err(GAAST_ERR_INVALID_ARGUMENT, "bad communicator argument");
+    if (int st = ensure_init()) return st;
+    std::string err;
+    if (comm_init(g_comm, id, rank, world, &err)) return rccl_err(err);
+    return GAAST_OK;
+}
+
+int gaast_hip_comm_destroy(void) {
+    if (int st = ensure_init()) return st;
+    std::string err;
+    if (comm_destroy(g_comm, &err)) return rccl_err(err);
+    return GAAST_OK;
+}
+
+int gaast_hip_comm_info(int* rank, int* world) {
+    if (!g_comm.active()) return rccl_err("no communicator: call gaast_hip_comm_init first");
+    if (rank) *rank = g_comm.rank;
+    if (world) *world = g_comm.world;
+    return GAAST_OK;
+}
+
+int gaast_hip_comm_count_ranks(int* n_ranks) {
+    if (!n_ranks) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    if (!g_comm.active()) return rccl_err("no communicator: call gaast_hip_comm_init first");
+    int64_t* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(int64_t)));
+    const int64_t one = 1;
+    int64_t got = 0;
+    std::string err;
+    hipError_t e = hipMemcpy(d, &one, sizeof(one), hipMemcpyHostToDevice);
+    int failed = 0;
+    if (e == hipSuccess) failed = comm_allreduce_sum_i64(g_comm, d, 1, &err);
+    if (e == hipSuccess && !failed) e = hipStreamSynchronize(g_comm.stream);
+    if (e == hipSuccess && !failed) e = hipMemcpy(&got, d, sizeof(got), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (failed) return rccl_err(err);
+    if (e != hipSuccess) return set_err(GAAST_ERR_HIP, std::string("comm_count_ranks: ") + hipGetErrorString(e));
+    *n_ranks = int(got);
+    return GAAST_OK;
+}
+
+int gaast_hip_gather_rows(gaast_hip_mv_t local, gaast_hip_mv_t gathered, const int64_t* counts, int root) {
+    if (int st = ensure_init()) return st;
+    if (int st = check_gather_args(local, gathered, counts, root)) return st;
+    hipEvent_t ev;
+    if (int st = chunk_event(0, &ev)) return st;
+    HIP_TRY(hipEventRecord(ev, g_stream));               // the rows are produced on the library stream
+    HIP_TRY(hipStreamWaitEvent(g_comm.stream, ev, 0));
+    if (int st = gather_chunk(local, gathered, counts, root, 1, 0)) return st;
+    return join_comm_stream();
+}
+
+int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inputs, gaast_hip_mv_t out,
+                          gaast_hip_mv_t gathered, const int64_t* counts, int root, int n_chunks) {
+    if (int st = ensure_init()) return st;
+    if (n_chunks < 1 || n_chunks > 1024) return set_err(GAAST_ERR_INVALID_ARGUMENT, "n_chunks out of range");
+    if (int st = check_gather_args(out, gathered, counts, root)) return st;
+    const int64_t batch = counts[g_comm.rank];
+    if (out->batch != batch) return set_err(GAAST_ERR_INVALID_ARGUMENT, "out must hold counts[rank] items");
+    std::vector<Bound> in_bound;
+    if (int st = bind_eval(prog, inputs, n_inputs, batch, out, in_bound)) return st;
+    // chunk c is computed on the library stream; its rows leave on the communicator's stream while chunk c + 1 is
+    // being computed.  Every rank walks all n_chunks steps (a rank with fewer items has empty chunks) so that
+    // sends and receives pair up.
+    for (int c = 0; c < n_chunks; ++c) {
+        int64_t lo, hi;
+        chunk_span(batch, n_chunks, c, &lo, &hi);
+        if (int st = eval_range(prog, in_bound, out, lo, hi - lo)) return st;
+        hipEvent_t ev;
+        if (int st = chunk_event(c, &ev)) return st;
+        HIP_TRY(hipEventRecord(ev, g_stream));
+        HIP_TRY(hipStreamWaitEvent(g_comm.stream, ev, 0));
+        if (int st = gather_chunk(out, gathered, counts, root, n_chunks, c)) return st;
+    }
+    return join_comm_stream();
 }
 
 }  // extern "C"

@@ -15,6 +15,14 @@ def shard_range(batch: int, rank: int, world: int):
     return start, min(start + per, batch)
 
 
+def chunk_span(count: int, n_chunks: int, c: int):
+    """[lo, hi) of chunk c when `count` items are cut into n_chunks contiguous chunks (the schedule of
+    gaast_hip_eval_gather, runtime.hip: chunk_span)."""
+    per = -(-count // n_chunks) if n_chunks else count
+    lo = min(c * per, count)
+    return lo, min(lo + per, count)
+
+
 def gather_rows(local_rows, batch: int, dst: int = 0, group=None):
     """Gather the per-rank result rows ([n_local, row_len] tensors) to `dst`, in item order.
 

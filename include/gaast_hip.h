@@ -17,7 +17,12 @@
  *    or a download makes results visible;
  *  - the caller owns handles, the library owns the device memory behind them, no host
  *    pointer is retained after a call returns;
- *  - one process drives one GPU (one rank per GPU; multi-GPU batches shard by item).
+ *  - one process drives one GPU (one rank per GPU; multi-GPU batches shard by item: the
+ *    "multi-GPU" section below is the only exchange between ranks);
+ *  - the library's state (device, stream, communicator, scratch buffers) is per process and
+ *    NOT synchronised: calls must come from one thread at a time.  Every entry point that
+ *    touches the GPU makes the library's device current for the calling thread first, so the
+ *    driving thread may change between calls (HIP's current device is per thread).
  *
  * Device storage of a batched multivector ("graded rows"): one row per batch item, a row
  * holds the dense per-grade component arrays of that item concatenated in ascending grade
@@ -43,9 +48,12 @@ typedef enum gaast_status {
     GAAST_OK = 0,
     GAAST_ERR_INVALID_PROGRAM = 1,  /* malformed flat program (reference: specialize.rs:104-117 asserts) */
     GAAST_ERR_MISSING_GRADE = 2,    /* reference panic: graded.rs:188,193 (grade absent from a buffer) */
-    GAAST_ERR_UNIMPLEMENTED = 3,    /* reference panic: eval.rs:112-113 todo!() for exp / log */
+    GAAST_ERR_UNIMPLEMENTED = 3,    /* reference panic: eval.rs:112-113 todo!() for exp / log; also returned by
+                                     * gaast_hip_program_create for a program that is valid in the reference but
+                                     * beyond this back end (e.g. a product whose operands exceed the LDS budget of
+                                     * every kernel): such a program is refused whole, never half-evaluated */
     GAAST_ERR_HIP = 4,              /* a HIP runtime call failed; see gaast_hip_last_error() */
-    GAAST_ERR_RCCL = 5,
+    GAAST_ERR_RCCL = 5,             /* an RCCL call failed / librccl could not be loaded / no communicator */
     GAAST_ERR_INVALID_ARGUMENT = 6,
     GAAST_ERR_NO_DEVICE = 7,        /* no gfx950 device / library not initialised */
     GAAST_ERR_OVERFLOW = 8          /* reference debug-build panic: eval.rs:90 `k - 1` with k == 0 */
@@ -126,6 +134,13 @@ typedef struct gaast_input_desc {
  * multiply-adds, all on the matrix cores).  Equal to eval.rs:61-86 in exact arithmetic; the error is bounded norm-wise,
  * |err_S| <= 64 eps(dtype) |A|_2 |B|_2, not per component.  Never selected without this flag. */
 #define GAAST_FLAG_SPINOR_GEMM 0x20u
+/* Debug hooks (explicit flags, no environment variables): */
+#define GAAST_FLAG_DEBUG_JIT_FAILS 0x40u      /* treat every run-time (hiprtc) compilation as failed: exercises the fallbacks */
+#define GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE 0x80u /* keep the generated kernel source: gaast_hip_program_jit_source() */
+/* OPT-IN extension with no reference behaviour (eval.rs:112-113 is todo!()): evaluate Exponential / Logarithm with the
+ * semantics the grade rules imply (grade_set.rs:181-197), see DESIGN.md.  Without the flag such programs report
+ * GAAST_ERR_UNIMPLEMENTED exactly where the reference panics. */
+#define GAAST_FLAG_EXP_LOG 0x100u
 
 typedef struct gaast_program_desc {
     int32_t vec_space_dim;      /* n */
@@ -143,7 +158,8 @@ typedef struct gaast_hip_program_s *gaast_hip_program_t;
 typedef struct gaast_hip_mv_s *gaast_hip_mv_t;
 
 /* ---- runtime ------------------------------------------------------------------------- */
-/* Selects the GPU this process drives (device_ids[0]; n_dev must be 1: one rank per GPU). */
+/* Selects the GPU this process drives (device_ids[0]; n_dev must be 1: one rank per GPU -- a multi-GPU job is one
+ * process per GPU joined by gaast_hip_comm_init below). */
 int gaast_hip_init(const int *device_ids, int n_dev);
 int gaast_hip_shutdown(void);
 /* Launch on an existing HIP stream (e.g. torch's current stream); NULL = default stream. */
@@ -160,6 +176,8 @@ int gaast_hip_program_output_info(gaast_hip_program_t prog, uint64_t *grade_mask
 /* number of kernel launches one eval issues, and a one-line description of launch `i` */
 int gaast_hip_program_num_launches(gaast_hip_program_t prog);
 const char *gaast_hip_program_launch_name(gaast_hip_program_t prog, int i);
+/* GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE: the HIP source generated for this program ("" if none). */
+const char *gaast_hip_program_jit_source(gaast_hip_program_t prog);
 
 /* ---- GradedDataMut on the device (graded.rs:51-79) ------------------------------------- */
 /* init_null_mv(dim, gs) for `batch` items: zero-filled rows (graded.rs:195-201). */
@@ -188,6 +206,42 @@ int gaast_hip_mv_zero(gaast_hip_mv_t mv);
  */
 int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t *inputs, int n_inputs,
                    int64_t batch, gaast_hip_mv_t out);
+
+/* ---- multi-GPU: one rank per GPU, batch sharded by item ------------------------------------ */
+/*
+ * The reference evaluates one input set per eval() and keeps no cross-item state (eval.rs:16), so a batch
+ * shards into contiguous item ranges with no data-path collective; the ONLY exchange is the gather of the
+ * result rows to one rank.  The library does that itself over RCCL (xGMI), so that a non-Python host (the
+ * Rust shim) needs nothing else: rank 0 calls gaast_hip_comm_unique_id and ships the 128 bytes to the other
+ * ranks by any channel (file, socket, MPI, torch.distributed); every rank then calls gaast_hip_comm_init
+ * (collective).  librccl is loaded on first use (dlopen), not at link time.
+ */
+#define GAAST_COMM_ID_BYTES 128
+int gaast_hip_comm_unique_id(void *id_out);
+int gaast_hip_comm_init(const void *id, int rank, int world);
+int gaast_hip_comm_destroy(void);
+/* rank / world of the communicator (GAAST_ERR_RCCL if there is none) */
+int gaast_hip_comm_info(int *rank, int *world);
+/* all-reduce(sum) of one 1 per rank over the communicator: how many ranks RCCL actually joined (synchronous) */
+int gaast_hip_comm_count_ranks(int *n_ranks);
+/*
+ * Gather result rows to `root`: rank r contributes the first counts[r] rows of `local` (contiguous rows:
+ * row_stride == row_len); on root, `gathered` receives them in rank order (item order of the global batch),
+ * rank r's rows starting at row counts[0] + ... + counts[r-1].  `gathered` is ignored on the other ranks (may
+ * be NULL).  The root receives from all peers concurrently (one direct peer-to-peer transfer per xGMI link,
+ * not a ring).  Asynchronous on the library streams like gaast_hip_eval.
+ */
+int gaast_hip_gather_rows(gaast_hip_mv_t local, gaast_hip_mv_t gathered, const int64_t *counts, int root);
+/*
+ * gaast_hip_eval + gather, overlapped: the local batch (counts[rank] items) is evaluated in `n_chunks`
+ * contiguous chunks and chunk k travels to `root` on a second stream while chunk k+1 is being computed.
+ * Equivalent to gaast_hip_eval(prog, inputs, n_inputs, counts[rank], out) followed by
+ * gaast_hip_gather_rows(out, gathered, counts, root).  `out` may be the rows of `gathered` that belong to the
+ * root itself (same device memory): the local copy is then skipped.
+ */
+int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t *inputs, int n_inputs,
+                          gaast_hip_mv_t out, gaast_hip_mv_t gathered, const int64_t *counts, int root,
+                          int n_chunks);
 
 #ifdef __cplusplus
 }

@@ -30,9 +30,48 @@ def test_cpu_baseline_fields():
     json.dumps(base)   # must be serialisable into the one JSON line
 
 
-def test_pmc_traffic_table_points_at_committed_profiles():
-    import os
+def test_traffic_is_reported_only_for_the_kernel_and_library_it_was_measured_with(monkeypatch, tmp_path):
+    """roofline.traffic comes from profiles/traffic.json (tools/pmc_traffic.py); a figure recorded for another kernel, or
+    with other kernel sources than the loaded library's, is withheld and flagged stale."""
+    import gaast_amd
+    rev = gaast_amd.lib().gaast_hip_version().decode()
+    table = {"r12:65536": {"kernel": "product_dense_mfma[gp n=12]", "library": rev, "bytes": 3.2e9, "source": "x"},
+             "r8:1048576": {"kernel": "product_dense_mfma[gp n=8]", "library": "some other build", "bytes": 3.2e9, "source": "y"}}
+    monkeypatch.setattr(bench, "_load_traffic_table", lambda: table)
+    assert bench._traffic_for("r12", 65536, ["product_dense_mfma[gp n=12]"]) == (3.2e9, "x", False)
+    assert bench._traffic_for("r12", 65536, ["product_dense[gp n=12]"]) == (None, "x", True)        # another kernel ran
+    assert bench._traffic_for("r8", 1 << 20, ["product_dense_mfma[gp n=8]"]) == (None, "y", True)   # kernels rebuilt since
+    assert bench._traffic_for("r12", 512, ["product_dense_mfma[gp n=12]"]) == (None, None, False)   # never measured
+
+
+def test_committed_traffic_table_is_well_formed():
+    for key, ent in bench._load_traffic_table().items():
+        workload, batch = key.split(":")
+        assert bench.workload_spec(workload)["n"] >= 1 and int(batch) > 0
+        assert ent["bytes"] > 0 and ent["kernel"] and ent["library"] and ent["source"]
+        assert abs(ent["bytes"] - (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024) < 1
+
+
+def test_pmc_traffic_tool_parses_rocprofv3_counter_csv(tmp_path, monkeypatch):
+    import csv, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for (workload, batch), (traffic, source) in bench.PMC_TRAFFIC.items():
-        assert traffic > 0 and os.path.exists(os.path.join(root, source)), source
-        assert bench.workload_spec(workload)["default_batch"] == batch
+    hdr = ["Correlation_Id", "Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    for d, counter, vals in (("f", "FETCH_SIZE", [1000.0, 1002.0, 1001.0]), ("w", "WRITE_SIZE", [500.0, 500.0, 500.0])):
+        os.makedirs(tmp_path / d / "host")
+        with open(tmp_path / d / "host" / "1_counter_collection.csv", "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(hdr)
+            wr.writerow([0, 0, "other_kernel", counter, 7.0])
+            for i, v in enumerate(vals):
+                wr.writerow([i + 1, i + 1, "void gaast::k_gp_mfma32<false, 256>(gaast::DenseArgs<float>)", counter, v])
+    # run the tool on a scratch copy of the repo layout (it writes profiles/traffic.json next to itself)
+    scratch = tmp_path / "repo"
+    os.makedirs(scratch / "tools")
+    os.makedirs(scratch / "profiles")
+    (scratch / "tools" / "pmc_traffic.py").write_text(open(os.path.join(root, "tools", "pmc_traffic.py")).read())
+    run = subprocess.run([sys.executable, str(scratch / "tools" / "pmc_traffic.py"), "--workload", "r12", "--batch", "65536",
+                          "--launch-name", "product_dense_mfma[gp n=12]", "--kernel", "k_gp_mfma32", "--fetch", str(tmp_path / "f"),
+                          "--write", str(tmp_path / "w"), "--revision", "rev-x"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    ent = json.load(open(scratch / "profiles" / "traffic.json"))["r12:65536"]
+    assert ent["bytes"] == (2 * 1001.0 + 500.0) * 1024 and ent["library"] == "rev-x"

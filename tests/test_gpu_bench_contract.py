@@ -28,3 +28,32 @@ def test_bench_prints_one_json_line(args, bound):
     r = d["roofline"]
     assert r["bound"] == bound and r["unit"] == ("TFLOP/s" if bound == "mfma" else "GB/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_bench_self_launches_two_ranks_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher: the parent starts the ranks before touching a GPU.  Rehearsal mode
+    (both ranks on this box's one GPU, gloo collectives) exercises the real N > 1 control flow: shards, the chunked
+    overlapped gather, max-over-ranks timing, one JSON line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GAAST_BENCH_REHEARSAL"] = "1"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "300"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["global_batch"] == 600 and d["rccl_ranks"] == 2 and "rehearsal" in d
+    assert d["config"]["shards"] == [300, 300]
+    g = d["gather"]
+    assert g["chunks"] == 4 and g["value_with_gather"] > 0 and g["value_with_blocking_gather"] > 0
+    assert g["bytes_per_rank"] == 300 * 4096 * 4
+
+
+def test_bench_default_multi_gpu_workload_is_config_4(monkeypatch):
+    """Without --batch, N > 1 runs BASELINE configs[3]: 1,048,576 input sets cut into contiguous shards."""
+    from gaast_amd.sharding import shard_range
+    spans = [shard_range(1 << 20, r, 8) for r in range(8)]
+    assert all(hi - lo == 131072 for lo, hi in spans)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "global_batch = 1 << 20" in src and "BASELINE configs[3]" in src

@@ -492,19 +492,28 @@ def test_spinor_flag_is_ignored_where_it_does_not_apply(name):
     _assert_map_equal(_hip_value(name, flags=ga.FLAG_SPINOR_GEMM), _hip_value(name))
 
 
-def test_hiprtc_failure_falls_back_to_kernels_that_need_no_compiler(monkeypatch):
-    """GAAST_TEST_HIPRTC_FAILS=1 makes every run-time compilation fail: small programs run on the LDS interpreter,
+def test_hiprtc_failure_falls_back_to_kernels_that_need_no_compiler():
+    """GAAST_FLAG_DEBUG_JIT_FAILS makes every run-time compilation fail: small programs run on the LDS interpreter,
     plans that only fit the specialised kernel are rebuilt unfused -- same bits either way."""
-    monkeypatch.setenv("GAAST_TEST_HIPRTC_FAILS", "1")
+    fl = ga.FLAG_EXACT_ORDER | ga.FLAG_DEBUG_JIT_FAILS
     for name in ("cfg5_sandwich", "r5_gp_full", "shared_subexpr"):
         alg, build = CASES[name]
-        spec = build(HipBackend(), np.random.default_rng(7)).specialize(alg, flags=ga.FLAG_EXACT_ORDER)
+        spec = build(HipBackend(), np.random.default_rng(7)).specialize(alg, flags=fl)
         got = spec.eval()
         assert not any("ast_jit" in l for l in spec.launches()), spec.launches()
         _assert_map_equal(got, _oracle_value(name))
     alg, build = CASES["r5_gp_full"]
-    spec = build(HipBackend(), np.random.default_rng(7)).specialize(alg, flags=ga.FLAG_EXACT_ORDER)
+    spec = build(HipBackend(), np.random.default_rng(7)).specialize(alg, flags=fl)
     assert any("product_ell" in l or "ast_fused" in l for l in spec.launches()), spec.launches()
+
+
+def test_kept_jit_source_is_the_program_in_reference_order():
+    """GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE: the generated kernel can be read back (and is empty without the flag)."""
+    alg, build = CASES["cfg5_sandwich"]
+    spec = build(HipBackend(), np.random.default_rng(7)).specialize(alg, flags=ga.FLAG_DEBUG_KEEP_JIT_SOURCE)
+    src = spec.jit_source()
+    assert "gaast_jit" in src and "acc = acc" in src
+    assert build(HipBackend(), np.random.default_rng(7)).specialize(alg).jit_source() == ""
 
 
 # ---- storage, errors, edges ------------------------------------------------------------------
