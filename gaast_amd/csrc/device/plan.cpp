@@ -538,9 +538,26 @@ struct Lowering {
         std::vector<gaast_comp_mul> generated;
         const gaast_comp_mul* muls = nd.comp_muls;
         uint64_t n_muls = nd.n_comp_muls;
+        {
+            // capability limits, checked BEFORE any table is generated: the list kernels stage both operand rows of
+            // an item in LDS, and the list itself has to fit the table budget
+            const size_t elem = plan.dtype == GAAST_F32 ? 4 : 8;
+            const size_t per_item = size_t(ll.row_len + lrr.row_len) * elem;
+            const bool fits_fused_slab = ll.row_len + lrr.row_len + lr.row_len < 4096;
+            if (per_item > kLdsBytes && !fits_fused_slab && plan.unsupported.empty())
+                plan.unsupported = "product operands of " + std::to_string(per_item) + " bytes per item exceed the " +
+                                   std::to_string(kLdsBytes) + "-byte LDS the list kernels stage them in";
+            if (n_muls > kMaxListEntries && plan.unsupported.empty())
+                plan.unsupported = "a comp-mul list of " + std::to_string(n_muls) + " entries exceeds this back end's table budget";
+            if (!plan.unsupported.empty()) return;
+        }
         if (!muls) {
             Selection sel{nd.product_kind, nullptr, nullptr};
             auto contribs = iter_contribs(omin, sel, lmin, rmin);
+            if (comp_mul_count(d.vec_space_dim, contribs) > kMaxListEntries && plan.unsupported.empty())
+                plan.unsupported = "a comp-mul list of " + std::to_string(comp_mul_count(d.vec_space_dim, contribs)) +
+                                   " entries exceeds this back end's table budget";
+            if (!plan.unsupported.empty()) return;
             generated.reserve(size_t(comp_mul_count(d.vec_space_dim, contribs)));
             for_each_comp_mul(bt, d.metric_diag, contribs,
                               [&](const gaast_comp_mul& m) { generated.push_back(m); });

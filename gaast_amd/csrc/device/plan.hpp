@@ -87,6 +87,11 @@ struct Step {
     void* d_i32 = nullptr;
 };
 
+// limits of this back end (gfx950): a product whose staged operands exceed the LDS of a CU, or whose comp-mul list
+// exceeds the table budget, is valid in the reference but refused by gaast_hip_program_create (UNIMPLEMENTED)
+constexpr size_t kLdsBytes = 160 * 1024;
+constexpr uint64_t kMaxListEntries = uint64_t(1) << 27;
+
 struct Plan {
     int n = 0;
     int dtype = GAAST_F64;
@@ -100,6 +105,7 @@ struct Plan {
     std::vector<Step> steps;
     int error = GAAST_OK;              // what the reference would have panicked with, at eval
     std::string error_msg;
+    std::string unsupported;           // non-empty: valid in the reference, beyond this back end (program_create fails)
     std::vector<char> slot_used;       // input slots some launch reads (the others may stay unbound)
     std::string jit_source_kept;       // GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE
 };

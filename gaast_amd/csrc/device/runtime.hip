@@ -582,6 +582,8 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
     } catch (const std::exception& ex) {
         return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
     }
+    // valid in the reference, beyond this back end: refused whole, here, never half-evaluated
+    if (!prog->plan.unsupported.empty()) return set_err(GAAST_ERR_UNIMPLEMENTED, prog->plan.unsupported);
     // hiprtc specialisation of fused plans, before anything is uploaded: a plan that can only run as the
     // specialised kernel is rebuilt without run-time compilation if the compiler is not available
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -608,6 +610,7 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         } catch (const std::exception& ex) {
             return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
         }
+        if (!prog->plan.unsupported.empty()) return set_err(GAAST_ERR_UNIMPLEMENTED, prog->plan.unsupported);
     }
     Plan& plan = prog->plan;
     auto layout_of = [&](BufRef r) -> Layout {

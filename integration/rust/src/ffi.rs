@@ -6,6 +6,8 @@ pub const GAAST_OK: c_int = 0;
 pub const GAAST_F64: c_int = 0;
 pub const GAAST_F32: c_int = 1;
 pub const GAAST_PROD_EXPLICIT: i32 = -1;
+pub const GAAST_PROD_GEOMETRIC: i32 = 0;
+pub const GAAST_COMM_ID_BYTES: usize = 128;
 
 // gaast_opcode, in the order of AstNode's variants (base_types.rs:8-30) + ScalarUnaryOp (:84-88)
 pub const OP_INPUT: i32 = 0;
@@ -68,6 +70,24 @@ pub struct GaastProgramDesc {
     pub flags: u32,
 }
 
+// Layout of the structs above as the C compiler lays them out (tests/cpp/abi_layout.c -> abi_layout.json, checked
+// against the header and the Python mirrors by tests/test_abi_layout.py).  A drift fails the Rust build here.
+const _: () = {
+    use std::mem::{align_of, size_of};
+    assert!(size_of::<GaastCompMul>() == 32 && align_of::<GaastCompMul>() == 8);
+    assert!(size_of::<GaastNodeDesc>() == 56);
+    assert!(size_of::<GaastInputDesc>() == 24);
+    assert!(size_of::<GaastProgramDesc>() == 56);
+};
+pub const LAYOUT_COMP_MUL_COEFF_OFFSET: usize = 24;
+pub const LAYOUT_NODE_DESC_MINIMAL_GRADE_MASK_OFFSET: usize = 16;
+pub const LAYOUT_NODE_DESC_N_COMP_MULS_OFFSET: usize = 40;
+pub const LAYOUT_NODE_DESC_COMP_MULS_OFFSET: usize = 48;
+pub const LAYOUT_INPUT_DESC_CONST_ROW_OFFSET: usize = 16;
+pub const LAYOUT_PROGRAM_DESC_NODES_OFFSET: usize = 24;
+pub const LAYOUT_PROGRAM_DESC_INPUTS_OFFSET: usize = 40;
+pub const LAYOUT_PROGRAM_DESC_FLAGS_OFFSET: usize = 48;
+
 pub type Program = *mut c_void;
 pub type Mv = *mut c_void;
 
@@ -85,6 +105,15 @@ extern "C" {
     pub fn gaast_hip_mv_upload(m: Mv, grade: c_int, host: *const c_void, count: i64) -> c_int;
     pub fn gaast_hip_mv_download(m: Mv, grade: c_int, host: *mut c_void, count: i64) -> c_int;
     pub fn gaast_hip_eval(p: Program, inputs: *const Mv, n_inputs: c_int, batch: i64, out: Mv) -> c_int;
+    // multi-GPU (one process per GPU): the gather of result rows over RCCL, see include/gaast_hip.h
+    pub fn gaast_hip_comm_unique_id(id_out: *mut c_void) -> c_int;
+    pub fn gaast_hip_comm_init(id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    pub fn gaast_hip_comm_destroy() -> c_int;
+    pub fn gaast_hip_comm_info(rank: *mut c_int, world: *mut c_int) -> c_int;
+    pub fn gaast_hip_comm_count_ranks(n_ranks: *mut c_int) -> c_int;
+    pub fn gaast_hip_gather_rows(local: Mv, gathered: Mv, counts: *const i64, root: c_int) -> c_int;
+    pub fn gaast_hip_eval_gather(p: Program, inputs: *const Mv, n_inputs: c_int, out: Mv, gathered: Mv,
+                                 counts: *const i64, root: c_int, n_chunks: c_int) -> c_int;
 }
 
 /// Turns a non-zero status into the panic the reference would have raised.

@@ -1,0 +1,148 @@
+/* A plain C host of the ABI (what a non-Python caller links against): #include "gaast_hip.h", -lgaast_hip, no ctypes,
+ * no torch.  Builds BASELINE config 5 (R X ~R in R^{4,1}, f64) BY HAND as the flat program the reference's public read
+ * API yields (specialize.rs:17-24, base_types.rs:8-55), binds per-grade slices the way GradedData::grade_slice hands
+ * them over (graded.rs:43-47), evaluates and writes the root's rows.
+ *
+ *     abi_host <in.bin> <out.bin> <batch> [gather]
+ *
+ * in.bin : batch x 16 doubles (R: grades 0, 2, 4 concatenated per item) then batch x 5 doubles (X: grade 1)
+ * out.bin: batch x 16 doubles (root: grades 1, 3, 5)
+ * gather : go through the multi-GPU entry points with a one-rank communicator (gaast_hip_eval_gather, 4 chunks)
+ * tests/test_gpu_abi_c_host.py compares out.bin with the oracle, bit for bit. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gaast_hip.h"
+
+#define TRY(call)                                                                             \
+    do {                                                                                      \
+        int st__ = (call);                                                                    \
+        if (st__ != GAAST_OK) {                                                               \
+            fprintf(stderr, "%s -> status %d: %s\n", #call, st__, gaast_hip_last_error());    \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: abi_host in.bin out.bin batch [gather]\n");
+        return 2;
+    }
+    const int64_t batch = atoll(argv[3]);
+    const int use_gather = argc > 4 && strcmp(argv[4], "gather") == 0;
+    const int n = 5;
+    const double metric[5] = {1.0, 1.0, 1.0, 1.0, -1.0};
+    const uint64_t EVEN = 0x15, VEC = 0x2, ODD = 0x2A; /* grades {0,2,4}, {1}, {1,3,5} */
+
+    /* post-order node list: R, X, R*X, ~R, (R*X)*~R; R is one shared node (Expr::clone shares the Rc, expr.rs:47-53) */
+    gaast_node_desc nodes[5];
+    memset(nodes, 0, sizeof nodes);
+    for (int i = 0; i < 5; ++i) {
+        nodes[i].child0 = nodes[i].child1 = -1;
+        nodes[i].vec_space_dim = n;
+        nodes[i].input_slot = -1;
+        nodes[i].product_kind = GAAST_PROD_EXPLICIT;
+    }
+    nodes[0].opcode = GAAST_OP_INPUT;   nodes[0].minimal_grade_mask = EVEN; nodes[0].input_slot = 0;
+    nodes[1].opcode = GAAST_OP_INPUT;   nodes[1].minimal_grade_mask = VEC;  nodes[1].input_slot = 1;
+    nodes[2].opcode = GAAST_OP_PRODUCT; nodes[2].minimal_grade_mask = ODD;  nodes[2].child0 = 0; nodes[2].child1 = 1;
+    nodes[2].product_kind = GAAST_PROD_GEOMETRIC; nodes[2].n_comp_muls = 80;   /* compact: the library regenerates the list */
+    nodes[3].opcode = GAAST_OP_REVERSE; nodes[3].minimal_grade_mask = EVEN; nodes[3].child0 = 0;
+    nodes[4].opcode = GAAST_OP_PRODUCT; nodes[4].minimal_grade_mask = ODD;  nodes[4].child0 = 2; nodes[4].child1 = 3;
+    nodes[4].product_kind = GAAST_PROD_GEOMETRIC; nodes[4].n_comp_muls = 256;
+
+    gaast_input_desc inputs[2];
+    memset(inputs, 0, sizeof inputs);
+    inputs[0].grade_mask = EVEN; inputs[0].storage_dim = n;
+    inputs[1].grade_mask = VEC;  inputs[1].storage_dim = n;
+
+    gaast_program_desc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.vec_space_dim = n;
+    desc.metric_diag = metric;
+    desc.dtype = GAAST_F64;
+    desc.n_nodes = 5;
+    desc.nodes = nodes;
+    desc.root = 4;
+    desc.n_inputs = 2;
+    desc.inputs = inputs;
+    desc.flags = 0;
+
+    const int dev = 0;
+    TRY(gaast_hip_init(&dev, 1));
+    printf("%s\n", gaast_hip_version());
+    gaast_hip_program_t prog = NULL;
+    TRY(gaast_hip_program_create(&desc, &prog));
+    uint64_t out_mask = 0;
+    int64_t out_len = 0;
+    TRY(gaast_hip_program_output_info(prog, &out_mask, &out_len));
+    if (out_mask != ODD || out_len != 16) {
+        fprintf(stderr, "unexpected root: mask %llx len %lld\n", (unsigned long long)out_mask, (long long)out_len);
+        return 1;
+    }
+    for (int i = 0; i < gaast_hip_program_num_launches(prog); ++i) printf("launch %d: %s\n", i, gaast_hip_program_launch_name(prog, i));
+
+    /* inputs: item-major rows in the file; handed over grade by grade, as grade_slice(k) would be */
+    double *R = malloc(sizeof(double) * 16 * (size_t)batch), *X = malloc(sizeof(double) * 5 * (size_t)batch);
+    double *out_rows = malloc(sizeof(double) * 16 * (size_t)batch);
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(R, sizeof(double), 16 * (size_t)batch, f) != 16 * (size_t)batch ||
+        fread(X, sizeof(double), 5 * (size_t)batch, f) != 5 * (size_t)batch) {
+        fprintf(stderr, "cannot read %s\n", argv[1]);
+        return 1;
+    }
+    fclose(f);
+    gaast_hip_mv_t mR = NULL, mX = NULL, mOut = NULL, mAll = NULL;
+    TRY(gaast_hip_mv_alloc(n, EVEN, batch, GAAST_F64, &mR));
+    TRY(gaast_hip_mv_alloc(n, VEC, batch, GAAST_F64, &mX));
+    TRY(gaast_hip_mv_alloc(n, ODD, batch, GAAST_F64, &mOut));
+    const int r_grades[3] = {0, 2, 4}, r_len[3] = {1, 10, 5}, r_off[3] = {0, 1, 11};
+    for (int g = 0; g < 3; ++g) {
+        double *slab = malloc(sizeof(double) * (size_t)r_len[g] * (size_t)batch);
+        for (int64_t i = 0; i < batch; ++i) memcpy(slab + i * r_len[g], R + i * 16 + r_off[g], sizeof(double) * (size_t)r_len[g]);
+        TRY(gaast_hip_mv_upload(mR, r_grades[g], slab, (int64_t)r_len[g] * batch));
+        free(slab);
+    }
+    TRY(gaast_hip_mv_upload(mX, 1, X, 5 * batch));
+
+    gaast_hip_mv_t ins[2];
+    ins[0] = mR;
+    ins[1] = mX;
+    gaast_hip_mv_t result = mOut;
+    if (use_gather) {
+        unsigned char id[GAAST_COMM_ID_BYTES];
+        int n_ranks = 0, rank = -1, world = -1;
+        TRY(gaast_hip_comm_unique_id(id));
+        TRY(gaast_hip_comm_init(id, 0, 1));
+        TRY(gaast_hip_comm_info(&rank, &world));
+        TRY(gaast_hip_comm_count_ranks(&n_ranks));
+        printf("communicator: rank %d of %d, %d rank(s) counted\n", rank, world, n_ranks);
+        if (n_ranks != 1) return 1;
+        TRY(gaast_hip_mv_alloc(n, ODD, batch, GAAST_F64, &mAll));
+        const int64_t counts[1] = {batch};
+        TRY(gaast_hip_eval_gather(prog, ins, 2, mOut, mAll, counts, 0, 4));
+        TRY(gaast_hip_gather_rows(mOut, mAll, counts, 0));     /* and once more as the blocking form */
+        result = mAll;
+    } else {
+        TRY(gaast_hip_eval(prog, ins, 2, batch, mOut));
+    }
+    TRY(gaast_hip_synchronize());
+    TRY(gaast_hip_mv_download_rows(result, out_rows, 16 * batch));
+    f = fopen(argv[2], "wb");
+    if (!f || fwrite(out_rows, sizeof(double), 16 * (size_t)batch, f) != 16 * (size_t)batch) {
+        fprintf(stderr, "cannot write %s\n", argv[2]);
+        return 1;
+    }
+    fclose(f);
+    if (use_gather) TRY(gaast_hip_comm_destroy());
+    TRY(gaast_hip_mv_free(mR));
+    TRY(gaast_hip_mv_free(mX));
+    TRY(gaast_hip_mv_free(mOut));
+    if (mAll) TRY(gaast_hip_mv_free(mAll));
+    TRY(gaast_hip_program_destroy(prog));
+    TRY(gaast_hip_shutdown());
+    free(R); free(X); free(out_rows);
+    printf("OK\n");
+    return 0;
+}

@@ -69,6 +69,105 @@ static void lower(gaast_expr_t e, int n, const double* metric, int dtype, uint32
     std::printf("ok  %s (%zu steps)\n", what, plan.steps.size());
 }
 
+// ---- the tables of a PRODUCT_DENSE step, executed on the CPU --------------------------------------------------
+// What the dense kernels compute, restated from the step's tables alone (operand maps with image positions and
+// negate bits, out_map with its sign bit, neg_lo / neg_hi / zero_hi of the PERMUTED basis), compared with the
+// reference's own comp-mul list for the same product.  Checks the host half of the basis permutation
+// (plan.cpp: dense_basis_permutation): blade bijection, reordering signs, permuted metric masks.
+static uint32_t vec_pos(uint32_t m) {
+    const uint32_t x = m >> 4, lo = m & 15;
+    return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
+}
+static uint32_t mfma_b_pos(uint32_t m) {
+    const uint32_t x = m >> 5, k = m & 31;
+    const uint32_t lq = ((k & 1) << 2) | (k >> 3);
+    return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
+}
+
+static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
+                                             const char* expect_step) {
+    gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
+    gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
+    gaast_spec_t spec = gaast_expr_specialize(e, n, metric, uint64_t(1) << 22);
+    CHECK(spec != nullptr);
+    if (!spec) return;
+    gaast_program_desc desc;
+    CHECK(gaast_spec_program_desc(spec, dtype, flags, &desc) == 0);
+    gaast::Plan plan;
+    gaast::build_plan(desc, plan);
+    const gaast::Step* st = nullptr;
+    for (const gaast::Step& s : plan.steps)
+        if (s.kind == gaast::Step::PRODUCT_DENSE && !s.use_spinor) st = &s;
+    CHECK(st != nullptr);
+    if (!st) {
+        std::printf("%s: no dense step\n", what);
+        gaast_spec_free(spec);
+        return;
+    }
+    CHECK(st->name.find(expect_step) != std::string::npos);
+    const uint32_t N = 1u << n;
+    const int L = st->use_mfma ? 5 : 4;
+    // operands: a fixed pseudo-random row each (exact small integers: every sum below is exact)
+    std::vector<double> lrow(N), rrow(N);
+    uint64_t x = 88172645463325252ULL;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return double(int(x % 17) - 8); };
+    for (uint32_t i = 0; i < N; ++i) lrow[i] = rnd();
+    for (uint32_t i = 0; i < N; ++i) rrow[i] = rnd();
+    // images in permuted-blade order
+    std::vector<uint32_t> inv_vec(N), inv_b(N);
+    for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
+    if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
+    auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
+        std::vector<double> img(N, 0.0);
+        for (uint32_t w : map) {
+            const uint32_t off = w & 0xffffu, pos = (w >> 16) & 0x7fffu;
+            const uint32_t blade = st->use_mfma ? (right ? inv_b[pos] : pos) : st->use_mfma16 ? (right ? inv_vec[pos] : pos) : inv_vec[pos];
+            img[blade] = (w >> 31) ? -row[off] : row[off];
+        }
+        return img;
+    };
+    const std::vector<double> A = image(st->u32_a, lrow, false), B = image(st->u32_b, rrow, true);
+    std::vector<double> Cp(N, 0.0);
+    const uint32_t lomask = (1u << L) - 1;
+    for (uint32_t pa = 0; pa < N; ++pa)
+        for (uint32_t pb = 0; pb < N; ++pb) {
+            int par = 0;
+            for (int p = 1; p < n; ++p)
+                if ((pa >> p) & 1u) par ^= __builtin_popcount(pb & ((1u << p) - 1u)) & 1;
+            const uint32_t sh = pa & pb;
+            par ^= __builtin_popcount((sh & lomask) & st->neg_lo) & 1;
+            par ^= __builtin_popcount((sh >> L) & st->neg_hi) & 1;
+            if ((sh >> L) & st->zero_hi) continue;
+            Cp[pa ^ pb] += (par ? -1.0 : 1.0) * A[pa] * B[pb];
+        }
+    std::vector<double> got(N, 0.0);
+    for (uint32_t m = 0; m < N; ++m) {
+        const int32_t w = st->i32_a[m];
+        if (w < 0) continue;
+        got[size_t(w & 0x3fffffff)] = (w & 0x40000000) ? -Cp[m] : Cp[m];
+    }
+    // the reference's list (specialize.rs:162-183), on graded rows
+    std::vector<double> want(N, 0.0);
+    std::vector<uint64_t> goff(size_t(n) + 2, 0);
+    for (int k = 0; k <= n; ++k) goff[size_t(k) + 1] = goff[size_t(k)] + gaast_n_choose_k(uint64_t(n), uint64_t(k));
+    const int root = gaast_spec_root(spec);
+    gaast_spec_node_info info;
+    CHECK(gaast_spec_node(spec, root, &info) == 0);
+    const gaast_comp_mul* muls = gaast_spec_comp_muls(spec, root);
+    CHECK(muls != nullptr && info.n_comp_muls == (uint64_t(1) << (2 * n)));
+    if (muls)
+        for (uint64_t i = 0; i < info.n_comp_muls; ++i) {
+            const gaast_comp_mul& m = muls[i];
+            want[goff[m.result_grade] + m.result_index] += lrow[goff[m.left_grade] + m.left_index] * rrow[goff[m.right_grade] + m.right_index] * m.coeff;
+        }
+    size_t bad = 0;
+    for (uint32_t i = 0; i < N; ++i) bad += got[i] != want[i];
+    if (bad) std::printf("%s: %zu of %u components differ\n", what, bad, N);
+    CHECK(bad == 0);
+    gaast_spec_free(spec);
+    std::printf("ok  %s (%s)\n", what, st->name.c_str());
+}
+
 int main() {
     const double euclid[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     const double cga[5] = {1, 1, 1, 1, -1};
@@ -141,6 +240,21 @@ int main() {
             lower(gaast_expr_product(a, b, kind), 4, euclid, GAAST_F64, 0, "r4 product kinds", nullptr);
         lower(gaast_expr_sub(gaast_expr_ginvol(a), gaast_expr_neg(gaast_expr_rev(b))), 4, euclid, GAAST_F64, 0, "unary chain", nullptr);
         lower(gaast_expr_vinv(gaast_expr_input(2, 0x2, 4)), 4, euclid, GAAST_F64, 0, "vinv", nullptr);
+    }
+    {   // dense tables under a basis permutation == the reference's list, for every kernel's table format
+        const double pga6[6] = {0, 1, 1, 1, 1, -1}, anti6[6] = {-1, 1, -1, -1, -1, 1}, sta6[6] = {-1, 1, 1, 1, 0, 1};
+        dense_tables_agree_with_the_list(6, euclid, GAAST_F64, 0, "dense tables n=6 euclid", "product_dense[gp n=6]");
+        dense_tables_agree_with_the_list(6, pga6, GAAST_F64, 0, "dense tables n=6 null vector first", "permuted basis");
+        dense_tables_agree_with_the_list(6, anti6, GAAST_F64, 0, "dense tables n=6 four negative lo vectors", "permuted basis");
+        dense_tables_agree_with_the_list(6, sta6, GAAST_F32, 0, "dense tables n=6 time first", "permuted basis");
+        const double pga8[8] = {0, 1, 1, 1, 1, 1, 1, 1}, neg8[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, mix8[8] = {1, 0, -1, 1, 0, -1, 1, -1};
+        dense_tables_agree_with_the_list(8, pga8, GAAST_F32, 0, "mfma16 tables n=8 null vector first", "product_dense_mfma");
+        dense_tables_agree_with_the_list(8, neg8, GAAST_F32, 0, "mfma16 tables Cl(0,8)", "product_dense_mfma[gp n=8]");
+        dense_tables_agree_with_the_list(8, mix8, GAAST_F32, 0, "mfma16 tables n=8 mixed", "permuted basis");
+        dense_tables_agree_with_the_list(8, neg8, GAAST_F64, 0, "vector tables Cl(0,8)", "product_dense[gp n=8]");
+        const double mix10[10] = {0, -1, 1, 1, -1, 1, 0, 1, -1, 1};
+        dense_tables_agree_with_the_list(10, mix10, GAAST_F32, 0, "mfma32 tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
+        dense_tables_agree_with_the_list(10, euclid, GAAST_F32, 0, "mfma32 tables n=10 euclid", "product_dense_mfma[gp n=10]");
     }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {

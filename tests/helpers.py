@@ -176,3 +176,19 @@ def gp_bits(n, metric_diag, A, B, absolute=False):
     if absolute:
         terms = np.abs(terms)
     return np.bincount((a ^ b).ravel(), weights=terms.ravel(), minlength=N)
+
+
+def abs_terms_bound(n, A_bits, B_bits):
+    """sum over all blade pairs landing on each output blade of |A[a]| |B[b]| (the XOR-convolution of |A| and |B|) by a
+    Walsh-Hadamard transform: O(n 2^n) instead of the 4^n table of gp_bits(absolute=True).  For metrics with entries
+    of modulus <= 1 it bounds sum |term| from above (null vectors only remove terms)."""
+    def wht(v):
+        v = np.array(v, dtype=np.float64)
+        h = 1
+        while h < v.size:
+            v = v.reshape(-1, 2, h)
+            v = np.concatenate([v[:, 0, :] + v[:, 1, :], v[:, 0, :] - v[:, 1, :]], axis=1).reshape(-1)
+            h *= 2
+        return v
+    N = 1 << n
+    return np.abs(wht(wht(np.abs(A_bits)) * wht(np.abs(B_bits))) / N)

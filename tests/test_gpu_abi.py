@@ -191,3 +191,70 @@ def test_q2_missing_grade_is_a_status():
         with pytest.raises(ga.GaastError) as ei:
             hip_eval_batch(build, 3, rows, 1)
         assert ei.value.status_name == "MISSING_GRADE"
+
+
+def test_a_program_beyond_the_back_end_is_refused_whole_at_program_create():
+    """n = 14: three middle grades times a full multivector stage 206 KB of operands per item (f64) -- more than the
+    160 KiB of LDS the list kernels have, and no dense kernel exists beyond n = 13.  The program is valid in the
+    reference; gaast_hip_program_create says UNIMPLEMENTED (not INVALID_PROGRAM, and not at eval time with half of
+    the launches already queued)."""
+    n = 14
+    a, b = ga.mv(ga.Input(0, [6, 7, 8], n)), ga.mv(ga.Input(1, full_grades(n), n))
+    spec = (a * b).specialize(n)
+    with pytest.raises(ga.GaastError) as ei:
+        spec.program()
+    assert ei.value.status_name == "UNIMPLEMENTED" and "LDS" in str(ei.value)
+    # the full product in f32 fits the LDS (128 KiB) but its 4^14-entry list exceeds the table budget
+    full = (ga.mv(ga.Input(0, full_grades(n), n)) * b).specialize(n, dtype=ga.F32)
+    with pytest.raises(ga.GaastError) as ei:
+        full.program()
+    assert ei.value.status_name == "UNIMPLEMENTED" and "table budget" in str(ei.value)
+    # ... while a product of the same algebra that does fit runs, bit-exact
+    rng = np.random.default_rng(14)
+    build = lambda B: B.input(0, [1], n) * B.input(1, [1, 2], n)
+    rows = {0: rows_of(n, [1], 5, rng), 1: rows_of(n, [1, 2], 5, rng)}
+    want, _ = oracle_eval_batch(build, n, rows, 5)
+    got, _, _ = hip_eval_batch(build, n, rows, 5)
+    assert np.array_equal(got, want)
+
+
+def test_wrapped_single_row_with_zero_stride_is_well_formed():
+    """gaast_hip_mv_wrap(batch = 1, row_stride = 0): the stride of a single row is normalised to the row length, so zero
+    fill, upload and download (2-D copies with pitch >= width) work"""
+    import torch
+    ga.init_device()
+    L = _lib.lib()
+    t = torch.full((1, 8), 3.0, dtype=torch.float64, device="cuda")
+    h = C.c_void_p()
+    _lib.check(L.gaast_hip_mv_wrap(C.c_void_p(t.data_ptr()), 3, 0xF, 1, _lib.F64, 0, C.byref(h)))
+    stride = C.c_int64()
+    _lib.check(L.gaast_hip_mv_info(h, None, None, None, None, None, C.byref(stride), None))
+    assert stride.value == 8
+    _lib.check(L.gaast_hip_mv_zero(h))
+    _lib.check(L.gaast_hip_synchronize())
+    assert float(t.abs().sum()) == 0.0
+    row = np.arange(8, dtype=np.float64)
+    _lib.check(L.gaast_hip_mv_upload_rows(h, row.ctypes.data_as(C.c_void_p), 8))
+    assert np.array_equal(t.cpu().numpy()[0], row)
+    _lib.check(L.gaast_hip_mv_free(h))
+
+
+def test_entry_points_make_the_library_device_current_on_any_thread():
+    """HIP's current device is per host thread: an eval driven from a second thread (a Rust worker, torch's autograd
+    thread) runs on the library's device and gives the same bits"""
+    import threading
+    rng = np.random.default_rng(3)
+    build = lambda B: (B.input(0, full_grades(3), 3) + B.input(1, full_grades(3), 3) * B.input(2, full_grades(3), 3)).g(2)
+    rows = {s: rows_of(3, full_grades(3), 100, rng) for s in range(3)}
+    want, _ = oracle_eval_batch(build, 3, rows, 100)
+    box = {}
+
+    def work():
+        try:
+            box["got"] = hip_eval_batch(build, 3, rows, 100)[0]
+        except Exception as e:      # pragma: no cover
+            box["err"] = e
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "err" not in box and np.array_equal(box["got"], want)

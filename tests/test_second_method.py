@@ -14,7 +14,9 @@ def _oracle_gp(n, metric, a, b, grades_a, grades_b):
     return spec.eval().to_dict()
 
 
-@pytest.mark.parametrize("metric", [[1.0] * 5, [1.0, 1.0, 1.0, 1.0, -1.0], [0.0, 1.0, 1.0], [2.0, -0.5, 3.0, 0.25]])
+@pytest.mark.parametrize("metric", [[1.0] * 5, [1.0, 1.0, 1.0, 1.0, -1.0], [0.0, 1.0, 1.0], [2.0, -0.5, 3.0, 0.25],
+                                    [1.0] * 6, [1.0, -1.0, 1.0, 0.0, -1.0, 1.0, 1.0], [1.0] * 8,
+                                    [-1.0, 1.0, 1.0, 0.0, 1.0, -1.0, 1.0, 1.0], [-1.0] * 8])
 def test_bitmask_convolution_matches_oracle(metric):
     n = len(metric)
     rng = np.random.default_rng(21)
