@@ -249,6 +249,12 @@ def main():
         from gaast_amd.launch import self_launch
         raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    # stdout carries exactly ONE JSON line: whatever the libraries underneath print there (gloo / RCCL banners) goes
+    # to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -565,7 +571,8 @@ def main():
             res["gather"] = gather
         if cpu is not None:
             res["cpu_baseline"] = cpu
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.barrier()
         if lib_comm:
