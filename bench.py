@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--gather-chunks", type=int, default=4)
     ap.add_argument("--no-alt", action="store_true", help="skip the opt-in matrix-representation side measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-item latency side measurement")
+    ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="extra GAAST_FLAG_* bits for the program (A/B measurements)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher: start the N ranks ourselves, BEFORE anything touches a GPU
@@ -342,7 +343,7 @@ def main():
     # one SpecializedAst (phases 1-3 on the host, once), one device program
     exprs = [ga.mv(ga.Input(s, g, n)) for s, g in enumerate(wl["inputs"])]
     t0 = time.time()
-    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=wl.get("flags", 0))
+    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=wl.get("flags", 0) | args.flags)
     spec.program()
     t_spec = time.time() - t0
     out_mask, out_len = spec.output_info()

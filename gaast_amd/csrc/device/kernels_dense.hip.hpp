@@ -514,8 +514,25 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // Operand images: A in plain blade order, B in the vector kernel's quad-rotated order; items are 2^(n+1) + 16
 // words apart so that the four items of a wave sit on different banks.
 // ------------------------------------------------------------------------------------------
-template <bool DEGENERATE, int NDIM>
-__global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
+// DPP lane permutations inside a row of 16 lanes (one item's lanes): lane i reads lane i ^ e.  quad_perm gives
+// e = 1, 2, 3, row_half_mirror e = 7, row_mirror e = 15; every e in 0..15 is (0 | 4 | 8 | 12) ^ (0..3).
+constexpr int DPP_QX1 = 0xB1, DPP_QX2 = 0x4E, DPP_QX3 = 0x1B, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, true));
+}
+template <int E>
+__device__ __forceinline__ uint32_t dpp_quad_xor(uint32_t v) {   // lane i <- lane i ^ E, E in 0..3
+    if constexpr (E == 0) return v;
+    else if constexpr (E == 1) return dpp_row<DPP_QX1>(v);
+    else if constexpr (E == 2) return dpp_row<DPP_QX2>(v);
+    else return dpp_row<DPP_QX3>(v);
+}
+
+// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): register prefetch of
+// the next group's rows.  Otherwise: the general staging of stage_operands (partial grade sets, strided / unaligned rows).
+template <bool DEGENERATE, int NDIM, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gp_mfma16(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int n = NDIM;                       // 8 or 9
@@ -525,19 +542,55 @@ __global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
     constexpr int GPB = 4 / WPG;                  // groups per workgroup
     constexpr int IPB = 4 * GPB;                  // items per workgroup
     constexpr int item_stride = 2 * N + 16;
+    constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row
+    constexpr int PF = IPB * COUNT4 / 256;        // pieces per thread and operand (4)
+    constexpr int IT_STEP = 256 / COUNT4;         // item distance between a thread's pieces
     const int tid = threadIdx.x;
-    const int64_t item0 = int64_t(blockIdx.x) * IPB;
-    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
-
-    if (!p.left_full || !p.right_full) {
-        for (int i = tid; i < nitems * item_stride; i += 256) smem[i] = 0.f;
-        __syncthreads();
+    const int64_t num_groups = (p.batch + IPB - 1) / IPB;
+    // Persistent workgroups.  Fast path (both operands hold every blade in consecutive, 16-byte aligned rows): the
+    // rows of the NEXT group of items are fetched into registers while the matrix cores work on the current one, so
+    // that the HBM latency of a group hides under the previous group's products.  A thread's pieces sit at the same
+    // place of every row it touches (256 is a multiple of COUNT4): its index-map words are loaded once.
+    constexpr bool fast = FAST;
+    const int my_j4 = tid % COUNT4, my_it = tid / COUNT4;
+    // byte address of each of the thread's 4 + 4 components inside the first item's images it touches (further items
+    // are a compile-time distance away), and their negate bits
+    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    if (fast) {
+        const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[my_j4], mr = reinterpret_cast<const uint4*>(p.right_map)[my_j4];
+        const uint32_t mls[4] = {ml.x, ml.y, ml.z, ml.w}, mrs[4] = {mr.x, mr.y, mr.z, mr.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            wa[c] = (((mls[c] >> 16) & 0x7fffu) + uint32_t(my_it * item_stride)) << 2;
+            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(my_it * item_stride + N)) << 2;
+            sa[c] = mls[c] & 0x80000000u;     // a folded Negation / Reverse / GradeInvolution, or the basis permutation's sign
+            sb[c] = mrs[c] & 0x80000000u;
+        }
     }
-    stage_operands<float, 256>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                               p.canon_left, smem, item_stride, nitems, tid);
-    stage_operands<float, 256>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                               p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
-    __syncthreads();
+    float4 pf_l[PF], pf_r[PF];
+    auto fetch = [&](int64_t g) {
+        const int64_t it0 = g * IPB;
+        const int cnt = int(p.batch - it0 < IPB ? p.batch - it0 : IPB);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int it = my_it + k * IT_STEP;
+            if (it < cnt) {
+                pf_l[k] = *reinterpret_cast<const float4*>(p.left + (it0 + it) * p.left_stride + (my_j4 << 2));
+                pf_r[k] = *reinterpret_cast<const float4*>(p.right + (it0 + it) * p.right_stride + (my_j4 << 2));
+            }
+        }
+    };
+    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float y = x[c];
+            if (canon) y = 0.f + y;           // the reference's zero-init + add_grades_from copy: 0.0 + x
+            y = __uint_as_float(__float_as_uint(y) ^ sg[c]);
+            *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * IT_STEP * item_stride * 4)) = y;
+        }
+    };
+    if (fast && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
 
     const int wave = tid >> 6, lane = tid & 63;
     const int grp = wave / WPG, tile = wave - grp * WPG;
@@ -547,7 +600,10 @@ __global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
     const float* Bs = As + N;
     const int c_hi = (tile << 4) | i;
 
-    uint32_t amask[16], aoff[16];
+    // The A operand of lane i for term k is +-A[a_hi][i ^ k]: the lane reads ITS OWN word A[a_hi][i] once per step and
+    // the 16 lanes of the item exchange them through DPP (no LDS gather, no address arithmetic): lane i <- lane i ^ k.
+    // amask[k]: sign of that operand, a lane constant (reordering sign of the lo bits, lo vectors that square to -1).
+    uint32_t amask[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int a_lo = i ^ k;
@@ -555,67 +611,120 @@ __global__ __launch_bounds__(256) void k_gp_mfma16(DenseArgs<float> p) {
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
         amask[k] = uint32_t(par) << 31;
-        aoff[k] = uint32_t(a_lo) << 2;
     }
-    float16v acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
-    auto one_step = [&](int a_hi) {
+    // block sign of every step, one bit per a_hi: (-1)^(u(a_hi) + parity(c_hi & M(a_hi))), and (DEGENERATE) the
+    // steps whose contribution to this lane's column vanishes
+    uint32_t sign_bits = 0, zero_bits = 0;
+#pragma unroll 1
+    for (int a_hi = 0; a_hi < H; ++a_hi) {
         uint32_t sp = uint32_t(a_hi) >> 1;
         sp ^= sp >> 1;
         sp ^= sp >> 2;
         sp ^= sp >> 4;
-        sp ^= sp >> 8;
         const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-        const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
-                            __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-        const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
-        float bscale = 1.f;
-        if (DEGENERATE) {
-            if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
-        }
-        const int x = a_hi ^ c_hi;
-        const int rot = (x >> 2) & 3;             // dense_lds_pos: quads of block x rotated by (x >> 2) & 3
-        const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 4));
-        float bv[16];
+        const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^ __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+        sign_bits |= ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << a_hi;
+        if (DEGENERATE) zero_bits |= ((uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? 1u : 0u) << a_hi;
+    }
+    const uint32_t* As_own = reinterpret_cast<const uint32_t*>(As) + i;
+    const unsigned char* Bs_b = reinterpret_cast<const unsigned char*>(Bs);
+    // B block x = a_hi ^ c_hi, its four 16-byte quads rotated by (x >> 2) & 3 (dense_lds_pos): the byte offset of
+    // logical quad q is (lane constant) ^ (step constant)
+    uint32_t bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4v v = bp[q ^ rot];
-            bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
-        }
-        const uint32_t abase = uint32_t(a_hi) << 6;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float a = *reinterpret_cast<const float*>(As_b + abase + aoff[k]);
-            a = __uint_as_float(__float_as_uint(a) ^ amask[k]);
-            float b = __uint_as_float(__float_as_uint(bv[k]) ^ bmask);
-            if (DEGENERATE) b *= bscale;
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0);
-        }
-    };
-    // (unrolling this loop makes the block index a constant but costs all the registers: 1 wave per SIMD, -40 %)
-    constexpr int half = H >> 1;
-#pragma unroll 1
-    for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
-#pragma unroll
-    for (int k = 0; k < 16; ++k)  // (-1)^(|a_hi| |k|) for odd |a_hi|
-        amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
-#pragma unroll 1
-    for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
-
-    // ---- results: register 4 b + r of lane 16 rg + j = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + j ----
+    for (int q = 0; q < 4; ++q) bq[q] = (uint32_t(c_hi) << 6) | (uint32_t((q ^ (c_hi >> 2)) & 3) << 4);
+    // where this lane's results go: register 4 b + r = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + (lane & 15)
     const int rg = lane >> 4;
-    const int32_t* om = p.out_map + (c_hi << 4);
+    int32_t om[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int item = grp * 4 + b;
-        if (item < nitems) {
-            float* orow = p.out + (item0 + item) * p.out_stride;
+    for (int r = 0; r < 4; ++r) om[r] = p.out_map[(c_hi << 4) + 4 * rg + r];
+
+    for (int64_t g = blockIdx.x; g < num_groups; g += gridDim.x) {
+        const int64_t item0 = g * IPB;
+        const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+        // ---- both operands of the group's items into their LDS images ----
+        if (fast) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) store_result<float>(orow, om[4 * rg + r], acc[4 * b + r], p.beta);
+            for (int k = 0; k < PF; ++k) {
+                const int sit = my_it + k * IT_STEP;
+                if (sit < nitems) {
+                    scatter4(k, pf_l[k], wa, sa, p.canon_left);
+                    scatter4(k, pf_r[k], wb, sb, p.canon_right);
+                }
+            }
+        } else {
+            if (!p.left_full || !p.right_full) {
+                for (int e = tid; e < nitems * item_stride; e += 256) smem[e] = 0.f;
+                __syncthreads();
+            }
+            stage_operands<float, 256>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, nitems, tid);
+            stage_operands<float, 256>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
         }
+        __syncthreads();
+        if (fast && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
+
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        auto one_step = [&](int a_hi) {
+            uint32_t sbit = ((sign_bits >> a_hi) & 1u) << 31;
+            float sgn = __uint_as_float(0x3f800000u | sbit);
+            if (DEGENERATE) {
+                if ((zero_bits >> a_hi) & 1u) sgn = 0.f;
+            }
+            const float2v s2 = float2v{sgn, sgn};
+            const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
+            float2v b2[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v v = *reinterpret_cast<const float4v*>(Bs_b + (bq[q] ^ sx));
+                b2[2 * q] = float2v{v.x, v.y} * s2;
+                b2[2 * q + 1] = float2v{v.z, v.w} * s2;
+            }
+            const uint32_t w0 = As_own[a_hi << 4];
+            const uint32_t t7 = dpp_row<DPP_ROW_HALF_MIRROR>(w0), t15 = dpp_row<DPP_ROW_MIRROR>(w0);
+            const uint32_t w4 = dpp_row<DPP_QX3>(t7), w8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15), w12 = dpp_row<DPP_QX3>(t15);
+            auto term = [&](auto ktag, uint32_t base) {
+                constexpr int k = decltype(ktag)::value;
+                const float a = __uint_as_float(dpp_quad_xor<(k & 3)>(base) ^ amask[k]);
+                const float b = (k & 1) ? b2[k >> 1].y : b2[k >> 1].x;
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0);
+            };
+            term(std::integral_constant<int, 0>{}, w0);   term(std::integral_constant<int, 1>{}, w0);
+            term(std::integral_constant<int, 2>{}, w0);   term(std::integral_constant<int, 3>{}, w0);
+            term(std::integral_constant<int, 4>{}, w4);   term(std::integral_constant<int, 5>{}, w4);
+            term(std::integral_constant<int, 6>{}, w4);   term(std::integral_constant<int, 7>{}, w4);
+            term(std::integral_constant<int, 8>{}, w8);   term(std::integral_constant<int, 9>{}, w8);
+            term(std::integral_constant<int, 10>{}, w8);  term(std::integral_constant<int, 11>{}, w8);
+            term(std::integral_constant<int, 12>{}, w12); term(std::integral_constant<int, 13>{}, w12);
+            term(std::integral_constant<int, 14>{}, w12); term(std::integral_constant<int, 15>{}, w12);
+        };
+        // (unrolling these loops makes the block index a constant but costs all the registers)
+        constexpr int half = H >> 1;
+#pragma unroll 1
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
+#pragma unroll
+        for (int k = 0; k < 16; ++k)  // (-1)^(|a_hi| |k|) for odd |a_hi|
+            amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
+#pragma unroll 1
+        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+#pragma unroll
+        for (int k = 0; k < 16; ++k)  // back to the even-|a_hi| pattern for the next group
+            amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
+
+        // ---- results -> graded rows ----
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int item = grp * 4 + b;
+            if (item < nitems) {
+                float* orow = p.out + (item0 + item) * p.out_stride;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_result<float>(orow, om[r], acc[4 * b + r], p.beta);
+            }
+        }
+        __syncthreads();   // the LDS images are rewritten by the next group
     }
 }
 

@@ -828,18 +828,51 @@ bool try_fuse(Plan& plan) {
             return std::string(buf);
         };
         auto var = [&](uint32_t i) { return "v" + std::to_string(i); };
+        // Persistent lanes: a lane walks the items lane, lane + grid, lane + 2 grid, ... and fetches the rows of its NEXT
+        // item into registers before it starts on the current one, so that the HBM latency of one item hides under
+        // the arithmetic of the previous (GAAST_FLAG_NO_PREFETCH: one item per lane, for A/B measurements).  A row
+        // shared by every item (stride 0) is fetched once.
+        const bool prefetch = !(plan.flags & GAAST_FLAG_NO_PREFETCH);
+        auto pvar = [&](size_t i, int c) { return "p" + std::to_string(i) + "_" + std::to_string(c); };
         src += std::string("typedef ") + ty + " T;\nextern \"C\" __global__ __launch_bounds__(256) void gaast_jit(";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i)
             src += "const T* __restrict__ in" + std::to_string(i) + ", long long s" + std::to_string(i) + ", ";
         src += "T* __restrict__ out, long long so, long long batch) {\n";
-        src += "  const long long item = blockIdx.x * 256LL + threadIdx.x;\n  if (item >= batch) return;\n";
+        src += "  long long item = blockIdx.x * 256LL + threadIdx.x;\n  if (item >= batch) return;\n";
+        if (prefetch) {
+            src += "  const long long grid = (long long)gridDim.x * 256LL;\n";
+            for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+                const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
+                src += "  T";
+                for (int c = 0; c < len; ++c) src += std::string(c ? ", " : " ") + pvar(i, c);
+                src += ";\n  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
+                for (int c = 0; c < len; ++c) src += "    " + pvar(i, c) + " = r[" + std::to_string(c) + "];\n";
+                src += "  }\n";
+            }
+            src += "  for (;;) {\n";
+        }
         for (int i = 0; i < slab; ++i) src += "  T " + var(uint32_t(i)) + " = 0;\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const Step::FusedInput& fi = f.fused_inputs[i];
             const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
-            src += "  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
-            for (int c = 0; c < len; ++c)
-                src += "    " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + r[" : " = r[") + std::to_string(c) + "];\n";
+            if (prefetch) {
+                for (int c = 0; c < len; ++c)
+                    src += "  " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + " : " = ") + pvar(i, c) + ";\n";
+            } else {
+                src += "  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
+                for (int c = 0; c < len; ++c)
+                    src += "    " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + r[" : " = r[") + std::to_string(c) + "];\n";
+                src += "  }\n";
+            }
+        }
+        if (prefetch) {
+            src += "  const long long nxt = item + grid;\n  if (nxt < batch) {\n";
+            for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+                const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
+                src += "    if (s" + std::to_string(i) + " != 0) { const T* r = in" + std::to_string(i) + " + nxt * s" + std::to_string(i) + ";\n";
+                for (int c = 0; c < len; ++c) src += "      " + pvar(i, c) + " = r[" + std::to_string(c) + "];\n";
+                src += "    }\n";
+            }
             src += "  }\n";
         }
         for (const Step& s : plan.steps) {
@@ -890,7 +923,9 @@ bool try_fuse(Plan& plan) {
         src += "  T* o = out + item * so;\n";
         for (int64_t c = 0; c < plan.out_layout.row_len; ++c)
             src += "  o[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
+        if (prefetch) src += "  if (nxt >= batch) break;\n  item = nxt;\n  }\n";
         src += "}\n";
+        f.jit_persistent = prefetch ? 1 : 0;
         f.jit_source = std::move(src);
     }
     f.fused_slab = slab;

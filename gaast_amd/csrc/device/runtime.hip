@@ -247,10 +247,18 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 s.threads = 256;
                 s.items_per_block = 4 * (4 / wpg);
                 s.lds = size_t(s.items_per_block) * size_t((2 << n) + 16) * sizeof(float);
-                auto kern = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8> : &k_gp_mfma16<false, 8>)
-                                   : (s.degenerate ? &k_gp_mfma16<true, 9> : &k_gp_mfma16<false, 9>);
-                s.kern[0] = reinterpret_cast<const void*>(kern);
-                return allow_lds(s.kern[0], s.lds);
+                // [0]: general staging; [1]: register prefetch, when both operands are full rows that turn out
+                // contiguous and 16-byte aligned at launch
+                using KernD = void (*)(DenseArgs<float>);
+                const KernD general = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8, false> : &k_gp_mfma16<false, 8, false>)
+                                             : (s.degenerate ? &k_gp_mfma16<true, 9, false> : &k_gp_mfma16<false, 9, false>);
+                const KernD fast = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8, true> : &k_gp_mfma16<false, 8, true>)
+                                          : (s.degenerate ? &k_gp_mfma16<true, 9, true> : &k_gp_mfma16<false, 9, true>);
+                s.kern[0] = reinterpret_cast<const void*>(general);
+                s.kern[1] = reinterpret_cast<const void*>(fast);
+                if (int st = allow_lds(s.kern[0], s.lds)) return st;
+                if (int st = allow_lds(s.kern[1], s.lds)) return st;
+                return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
             }
         }
         const int lpi = 1 << (n - 4);
@@ -415,7 +423,8 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             blocks = int64_t(g_num_cu) * s.blocks_per_cu;
             if (blocks > groups) blocks = groups;
         }
-        hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[0])), dim3(unsigned(blocks)),
+        const bool prefetch = s.use_mfma16 && p.left_contig && p.right_contig && p.left_full && p.right_full;
+        hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);
         break;
     }
@@ -452,6 +461,11 @@ bool jit_compile(Step& s, std::string* log) {
     }
     s.jit_module = mod;
     s.jit_function = fn;
+    if (s.jit_persistent) {  // resident grid of the grid-stride (prefetching) form
+        int per_cu = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        s.blocks_per_cu = per_cu;
+    }
     return true;
 }
 
@@ -474,7 +488,9 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     args.push_back(&optr);
     args.push_back(&ostride);
     args.push_back(&b);
-    const unsigned blocks = unsigned((batch + 255) / 256);
+    int64_t nblocks = (batch + 255) / 256;
+    if (s.jit_persistent && nblocks > int64_t(g_num_cu) * s.blocks_per_cu) nblocks = int64_t(g_num_cu) * s.blocks_per_cu;
+    const unsigned blocks = unsigned(nblocks);
     HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, 256, 1, 1, 0, g_stream,
                                   args.data(), nullptr));
     (void)plan;
