@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgaast_hip.so")
+# GAAST_HIP_LIB: another build of the same library (kernel A/B measurements: make KFLAGS=... OUTDIR=...)
+LIB_PATH = os.environ.get("GAAST_HIP_LIB") or os.path.join(_HERE, "lib", "libgaast_hip.so")
 
 GAAST_OK = 0
 STATUS_NAMES = {1: "INVALID_PROGRAM", 2: "MISSING_GRADE", 3: "UNIMPLEMENTED", 4: "HIP", 5: "RCCL",

@@ -3,6 +3,17 @@
 #pragma once
 #include "kernels_common.hip.hpp"
 
+// build-time A/B switches of the matrix-core kernels (defaults = the measured best)
+#ifndef GAAST_MFMA32_DPP
+#define GAAST_MFMA32_DPP 0
+#endif
+#ifndef GAAST_MFMA16_BSIGN_MUL
+#define GAAST_MFMA16_BSIGN_MUL 1
+#endif
+#ifndef GAAST_DENSE_NO_CANON
+#define GAAST_DENSE_NO_CANON 0
+#endif
+
 namespace gaast {
 
 // ------------------------------------------------------------------------------------------
@@ -383,6 +394,21 @@ __device__ __forceinline__ constexpr int lo5_reorder_parity(int a, int b) {
     return par;
 }
 
+// DPP lane permutations inside a row of 16 lanes (one item's lanes): lane i reads lane i ^ e.  quad_perm gives
+// e = 1, 2, 3, row_half_mirror e = 7, row_mirror e = 15; every e in 0..15 is (0 | 4 | 8 | 12) ^ (0..3).
+constexpr int DPP_QX1 = 0xB1, DPP_QX2 = 0x4E, DPP_QX3 = 0x1B, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, true));
+}
+template <int E>
+__device__ __forceinline__ uint32_t dpp_quad_xor(uint32_t v) {   // lane i <- lane i ^ E, E in 0..3
+    if constexpr (E == 0) return v;
+    else if constexpr (E == 1) return dpp_row<DPP_QX1>(v);
+    else if constexpr (E == 2) return dpp_row<DPP_QX2>(v);
+    else return dpp_row<DPP_QX3>(v);
+}
+
 // LDS position of blade m inside the B image: block x = m >> 5; inside it the components are
 // de-interleaved by the parity of k = m & 31 (even k first), 8 quads rotated by (x >> 1) & 7.
 __device__ __forceinline__ int mfma_b_pos(int m) {
@@ -427,6 +453,78 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         const int i = lane & 31, h = lane >> 5;
         const int c_hi = (tile << 5) | i;
 
+#if GAAST_MFMA32_DPP
+        // The A operand of lane (h, i) for term s2 is +-A[a_hi][i ^ k], k = 2 s2 + h.  The lane reads TWO words of the
+        // block once per step, A[i ^ h] and A[i ^ h ^ 16], and the lanes of a 16-lane row exchange them through DPP:
+        // A[i ^ (2 s2 + h)] is what lane (h, i ^ (2 s2 & 15)) read first (s2 < 8) or second (s2 >= 8) -- no LDS gather
+        // and no address arithmetic per term.  amask[s2]: sign of that operand, a lane constant.
+        uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int k = 2 * s2 + h;
+            const int a_lo = i ^ k;
+            int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
+            for (int pp = 1; pp < 5; ++pp)
+                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+            amask[s2] = uint32_t(par) << 31;
+        }
+        const uint32_t* As_own0 = reinterpret_cast<const uint32_t*>(As) + (i ^ h);
+        const uint32_t* As_own1 = reinterpret_cast<const uint32_t*>(As) + (i ^ h ^ 16);
+
+        // one accumulator chain per wave: a dependent f32 MFMA issues back to back; bitwise vector instructions issue
+        // beside the chain (tools/microbench/mfma16_loop.hip), LDS -> VGPR operand reads cost matrix-pipe time
+        // (tools/microbench/mfma_rate.hip)
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        auto one_step = [&](int a_hi) {
+            // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
+            uint32_t sp = uint32_t(a_hi) >> 1;
+            sp ^= sp >> 1;
+            sp ^= sp >> 2;
+            sp ^= sp >> 4;
+            sp ^= sp >> 8;
+            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+            const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
+            uint32_t keep = 0xffffffffu;
+            if (DEGENERATE) {
+                if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) keep = 0u;
+            }
+            const int x = a_hi ^ c_hi;
+            const int rot = (x >> 1) & 7;
+            const uint4* bp = reinterpret_cast<const uint4*>(Bs + (x << 5));
+            uint32_t bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = bp[((h << 2) | q) ^ rot];
+                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+            }
+            const uint32_t v0 = As_own0[a_hi << 5], v1 = As_own1[a_hi << 5];
+            // lane i <- lane i ^ e for e = 4, 8, 12 (e = 2 and the combinations ride on the xor itself)
+            const uint32_t t7a = dpp_row<DPP_ROW_HALF_MIRROR>(v0), t15a = dpp_row<DPP_ROW_MIRROR>(v0);
+            const uint32_t a4 = dpp_row<DPP_QX3>(t7a), a8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15a), a12 = dpp_row<DPP_QX3>(t15a);
+            const uint32_t t7b = dpp_row<DPP_ROW_HALF_MIRROR>(v1), t15b = dpp_row<DPP_ROW_MIRROR>(v1);
+            const uint32_t b4 = dpp_row<DPP_QX3>(t7b), b8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15b), b12 = dpp_row<DPP_QX3>(t15b);
+            auto term = [&](auto stag, uint32_t base) {
+                constexpr int s2 = decltype(stag)::value;   // lane exchange distance (2 s2) & 15 = base distance ^ (0 | 2)
+                const float a = __uint_as_float(dpp_quad_xor<((2 * s2) & 3)>(base) ^ amask[s2]);
+                uint32_t b = bv[s2] ^ bmask;
+                if (DEGENERATE) b &= keep;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(b), acc, 0, 0, 0);
+            };
+            term(std::integral_constant<int, 0>{}, v0);   term(std::integral_constant<int, 1>{}, v0);
+            term(std::integral_constant<int, 2>{}, a4);   term(std::integral_constant<int, 3>{}, a4);
+            term(std::integral_constant<int, 4>{}, a8);   term(std::integral_constant<int, 5>{}, a8);
+            term(std::integral_constant<int, 6>{}, a12);  term(std::integral_constant<int, 7>{}, a12);
+            term(std::integral_constant<int, 8>{}, v1);   term(std::integral_constant<int, 9>{}, v1);
+            term(std::integral_constant<int, 10>{}, b4);  term(std::integral_constant<int, 11>{}, b4);
+            term(std::integral_constant<int, 12>{}, b8);  term(std::integral_constant<int, 13>{}, b8);
+            term(std::integral_constant<int, 14>{}, b12); term(std::integral_constant<int, 15>{}, b12);
+        };
+#else
         // lane constants: sign masks of the A operand for both parities of |a_hi|, and the
         // byte offset of A[i ^ k] inside a block, for k = 2s + h
         uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
@@ -485,6 +583,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
         };
+#endif
         const int half = H >> 1;
         for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
 #pragma unroll
@@ -514,21 +613,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // Operand images: A in plain blade order, B in the vector kernel's quad-rotated order; items are 2^(n+1) + 16
 // words apart so that the four items of a wave sit on different banks.
 // ------------------------------------------------------------------------------------------
-// DPP lane permutations inside a row of 16 lanes (one item's lanes): lane i reads lane i ^ e.  quad_perm gives
-// e = 1, 2, 3, row_half_mirror e = 7, row_mirror e = 15; every e in 0..15 is (0 | 4 | 8 | 12) ^ (0..3).
-constexpr int DPP_QX1 = 0xB1, DPP_QX2 = 0x4E, DPP_QX3 = 0x1B, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_row(uint32_t v) {
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, true));
-}
-template <int E>
-__device__ __forceinline__ uint32_t dpp_quad_xor(uint32_t v) {   // lane i <- lane i ^ E, E in 0..3
-    if constexpr (E == 0) return v;
-    else if constexpr (E == 1) return dpp_row<DPP_QX1>(v);
-    else if constexpr (E == 2) return dpp_row<DPP_QX2>(v);
-    else return dpp_row<DPP_QX3>(v);
-}
-
 // FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): register prefetch of
 // the next group's rows.  Otherwise: the general staging of stage_operands (partial grade sets, strided / unaligned rows).
 template <bool DEGENERATE, int NDIM, bool FAST>
@@ -585,7 +669,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float y = x[c];
+#if !GAAST_DENSE_NO_CANON
             if (canon) y = 0.f + y;           // the reference's zero-init + add_grades_from copy: 0.0 + x
+#endif
             y = __uint_as_float(__float_as_uint(y) ^ sg[c]);
             *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * IT_STEP * item_stride * 4)) = y;
         }
@@ -669,19 +755,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         auto one_step = [&](int a_hi) {
-            uint32_t sbit = ((sign_bits >> a_hi) & 1u) << 31;
-            float sgn = __uint_as_float(0x3f800000u | sbit);
-            if (DEGENERATE) {
-                if ((zero_bits >> a_hi) & 1u) sgn = 0.f;
-            }
-            const float2v s2 = float2v{sgn, sgn};
+            // block sign and (DEGENERATE) block mask of this lane's B block: integer operations only -- bitwise vector
+            // instructions issue beside the matrix-core chain, floating-point ones (a multiply by +-1) do not
+            // (tools/microbench/mfma16_loop.hip)
+            const uint32_t sbit = ((sign_bits >> a_hi) & 1u) << 31;
+            uint32_t keep = 0xffffffffu;
+            if (DEGENERATE) keep = ((zero_bits >> a_hi) & 1u) ? 0u : 0xffffffffu;
+#if GAAST_MFMA16_BSIGN_MUL
+            float sg1 = __uint_as_float(0x3f800000u | sbit);
+            if (DEGENERATE) sg1 = keep ? sg1 : 0.f;
+            const float2v sgn2 = float2v{sg1, sg1};
+#endif
             const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
-            float2v b2[8];
+            uint32_t bw[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4v v = *reinterpret_cast<const float4v*>(Bs_b + (bq[q] ^ sx));
-                b2[2 * q] = float2v{v.x, v.y} * s2;
-                b2[2 * q + 1] = float2v{v.z, v.w} * s2;
+                const uint4 v = *reinterpret_cast<const uint4*>(Bs_b + (bq[q] ^ sx));
+                bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
             }
             const uint32_t w0 = As_own[a_hi << 4];
             const uint32_t t7 = dpp_row<DPP_ROW_HALF_MIRROR>(w0), t15 = dpp_row<DPP_ROW_MIRROR>(w0);
@@ -689,8 +779,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             auto term = [&](auto ktag, uint32_t base) {
                 constexpr int k = decltype(ktag)::value;
                 const float a = __uint_as_float(dpp_quad_xor<(k & 3)>(base) ^ amask[k]);
-                const float b = (k & 1) ? b2[k >> 1].y : b2[k >> 1].x;
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0);
+#if GAAST_MFMA16_BSIGN_MUL
+                const float2v bp2 = float2v{__uint_as_float(bw[k & ~1]), __uint_as_float(bw[k | 1])} * sgn2;
+                const float bf = (k & 1) ? bp2.y : bp2.x;
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, bf, acc, 0, 0, 0);
+#else
+                uint32_t b = bw[k] ^ sbit;
+                if (DEGENERATE) b &= keep;
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, __uint_as_float(b), acc, 0, 0, 0);
+#endif
             };
             term(std::integral_constant<int, 0>{}, w0);   term(std::integral_constant<int, 1>{}, w0);
             term(std::integral_constant<int, 2>{}, w0);   term(std::integral_constant<int, 3>{}, w0);
