@@ -828,51 +828,110 @@ bool try_fuse(Plan& plan) {
             return std::string(buf);
         };
         auto var = [&](uint32_t i) { return "v" + std::to_string(i); };
-        // Persistent lanes: a lane walks the items lane, lane + grid, lane + 2 grid, ... and fetches the rows of its NEXT
-        // item into registers before it starts on the current one, so that the HBM latency of one item hides under
-        // the arithmetic of the previous (GAAST_FLAG_NO_PREFETCH: one item per lane, for A/B measurements).  A row
-        // shared by every item (stride 0) is fetched once.
-        const bool prefetch = !(plan.flags & GAAST_FLAG_NO_PREFETCH);
-        auto pvar = [&](size_t i, int c) { return "p" + std::to_string(i) + "_" + std::to_string(c); };
-        src += std::string("typedef ") + ty + " T;\nextern \"C\" __global__ __launch_bounds__(256) void gaast_jit(";
+        // Row I/O.  lane <-> item, but a lane reading ITS row with 16-byte accesses makes every wave instruction touch 64
+        // different 128-byte lines: the CU's L1 then spends a cycle pair per line for 16 useful bytes and bounds the kernel
+        // (config 5: 56 % of HBM peak with the vector units 30 % busy).  So a wave (= a workgroup of 64 lanes) moves the
+        // rows of its 64 items as ONE contiguous span with fully coalesced 16-byte accesses and transposes through LDS:
+        // rows padded to an odd number of 16-byte units, so that both the span-ordered and the row-per-lane accesses are
+        // conflict-free.  Used per operand when its rows are contiguous (stride == length) and 16-byte aligned and the wave
+        // is full; otherwise (shared rows, strided or unaligned wrapped memory, the last partial wave) the lane reads its row
+        // directly.  GAAST_FLAG_NO_COALESCE: always the direct form (A/B measurements).
+        const size_t esz = plan.dtype == GAAST_F32 ? 4 : 8;
+        const int epc = int(16 / esz);                                   // elements per 16-byte chunk
+        auto padded_len = [&](int len) {                                 // row length in LDS, elements
+            size_t padb = (size_t(len) * esz + 15) / 16 * 16;
+            if ((padb / 16) % 2 == 0) padb += 16;
+            return int(padb / esz);
+        };
+        // which operands go through LDS: largest rows first, within a budget that keeps 16 waves per CU resident
+        // (160 KiB / 16 = 10 KiB per wave); the result rows reuse the operands' space.  Operands left out (and rows
+        // too long for the budget) are read by their lanes directly.
+        const size_t lds_budget = (plan.flags & GAAST_FLAG_DEBUG_LDS_12K) ? 12 * 1024 + 256 : 10 * 1024;
+        std::vector<int> lds_off(f.fused_inputs.size(), -1);
+        size_t lds_in = 0;
+        {
+            std::vector<size_t> order(f.fused_inputs.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+                return plan.input_layouts[size_t(f.fused_inputs[x].slot)].row_len > plan.input_layouts[size_t(f.fused_inputs[y].slot)].row_len;
+            });
+            for (size_t i : order) {
+                const size_t need = size_t(64) * size_t(padded_len(int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len))) * esz;
+                if (lds_in + need > lds_budget) continue;
+                lds_off[i] = int(lds_in);
+                lds_in += need;
+            }
+        }
+        const int out_len = int(plan.out_layout.row_len);
+        const size_t lds_out_need = size_t(64) * size_t(padded_len(out_len)) * esz;
+        const bool out_via_lds = lds_out_need <= lds_budget;
+        const size_t lds_total = std::max(lds_in, out_via_lds ? lds_out_need : size_t(0));
+        const bool coalesce = !(plan.flags & GAAST_FLAG_NO_COALESCE) && lds_total > 0;
+        const int threads = coalesce ? 64 : 256;
+        src += std::string("typedef ") + ty + " T;\n";
+        src += std::string("typedef ") + ty + " VT __attribute__((ext_vector_type(" + std::to_string(epc) + ")));\n";
+        src += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ") void gaast_jit(";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i)
             src += "const T* __restrict__ in" + std::to_string(i) + ", long long s" + std::to_string(i) + ", ";
         src += "T* __restrict__ out, long long so, long long batch) {\n";
-        src += "  long long item = blockIdx.x * 256LL + threadIdx.x;\n  if (item >= batch) return;\n";
-        if (prefetch) {
-            src += "  const long long grid = (long long)gridDim.x * 256LL;\n";
-            for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
-                const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
-                src += "  T";
-                for (int c = 0; c < len; ++c) src += std::string(c ? ", " : " ") + pvar(i, c);
-                src += ";\n  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
-                for (int c = 0; c < len; ++c) src += "    " + pvar(i, c) + " = r[" + std::to_string(c) + "];\n";
-                src += "  }\n";
-            }
-            src += "  for (;;) {\n";
+        if (coalesce) {
+            src += "  __shared__ __attribute__((aligned(16))) unsigned char lds[" + std::to_string(lds_total) + "];\n";
+            src += "  const int lane = threadIdx.x;\n  const long long item0 = blockIdx.x * 64LL;\n";
+            src += "  const long long item = item0 + lane;\n  const bool live = item < batch;\n  const bool full = item0 + 64 <= batch;\n";
+        } else {
+            src += "  const long long item = blockIdx.x * 256LL + threadIdx.x;\n  if (item >= batch) return;\n";
         }
         for (int i = 0; i < slab; ++i) src += "  T " + var(uint32_t(i)) + " = 0;\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const Step::FusedInput& fi = f.fused_inputs[i];
             const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
-            if (prefetch) {
+            const std::string I = std::to_string(i);
+            auto assign = [&](const std::string& from_prefix, const std::string& indent) {
                 for (int c = 0; c < len; ++c)
-                    src += "  " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + " : " = ") + pvar(i, c) + ";\n";
-            } else {
-                src += "  { const T* r = in" + std::to_string(i) + " + item * s" + std::to_string(i) + ";\n";
-                for (int c = 0; c < len; ++c)
-                    src += "    " + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + r[" : " = r[") + std::to_string(c) + "];\n";
+                    src += indent + var(uint32_t(fi.base + c)) + (fi.canon ? " = T(0) + " : " = ") + from_prefix + "[" + std::to_string(c) + "];\n";
+            };
+            if (!coalesce) {
+                src += "  { const T* r = in" + I + " + item * s" + I + ";\n";
+                assign("r", "    ");
                 src += "  }\n";
+                continue;
             }
-        }
-        if (prefetch) {
-            src += "  const long long nxt = item + grid;\n  if (nxt < batch) {\n";
-            for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
-                const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
-                src += "    if (s" + std::to_string(i) + " != 0) { const T* r = in" + std::to_string(i) + " + nxt * s" + std::to_string(i) + ";\n";
-                for (int c = 0; c < len; ++c) src += "      " + pvar(i, c) + " = r[" + std::to_string(c) + "];\n";
+            if (lds_off[i] < 0) {   // not staged: the lane reads its own row
+                src += "  if (live) { const T* r = in" + I + " + item * s" + I + ";\n";
+                assign("r", "    ");
+                src += "  }\n";
+                continue;
+            }
+            const int plen = padded_len(len);
+            const int nch = 64 * len / epc;                  // 16-byte chunks of the wave's span (64 * len * esz is a multiple of 256)
+            const int per_lane = (nch + 63) / 64;
+            const bool whole = (size_t(len) * esz) % 16 == 0;   // a chunk never straddles two rows
+            src += "  if (full && s" + I + " == " + std::to_string(len) + " && (((unsigned long long)in" + I + ") & 15ull) == 0) {\n";
+            src += "    const VT* src" + I + " = (const VT*)(in" + I + " + item0 * " + std::to_string(len) + ");\n";
+            src += "    T* img = (T*)(lds + " + std::to_string(lds_off[i]) + ");\n";
+            for (int j = 0; j < per_lane; ++j) src += "    VT c" + std::to_string(j) + ";\n";
+            for (int j = 0; j < per_lane; ++j) {
+                const bool guard = (j + 1) * 64 > nch;
+                src += std::string("    ") + (guard ? "if (lane + " + std::to_string(64 * j) + " < " + std::to_string(nch) + ") " : "") + "c" +
+                       std::to_string(j) + " = src" + I + "[lane + " + std::to_string(64 * j) + "];\n";
+            }
+            for (int j = 0; j < per_lane; ++j) {
+                const bool guard = (j + 1) * 64 > nch;
+                src += std::string("    ") + (guard ? "if (lane + " + std::to_string(64 * j) + " < " + std::to_string(nch) + ") " : "") + "{ const int el = (lane + " +
+                       std::to_string(64 * j) + ") * " + std::to_string(epc) + ";\n";
+                if (whole) {
+                    src += "      *(VT*)(img + (el / " + std::to_string(len) + ") * " + std::to_string(plen) + " + el % " + std::to_string(len) + ") = c" + std::to_string(j) + ";\n";
+                } else {
+                    for (int e = 0; e < epc; ++e)
+                        src += "      img[((el + " + std::to_string(e) + ") / " + std::to_string(len) + ") * " + std::to_string(plen) + " + (el + " + std::to_string(e) + ") % " +
+                               std::to_string(len) + "] = c" + std::to_string(j) + "[" + std::to_string(e) + "];\n";
+                }
                 src += "    }\n";
             }
+            src += "    __syncthreads();\n    const T* r = img + lane * " + std::to_string(plen) + ";\n";
+            assign("r", "    ");
+            src += "  } else if (live) {\n    const T* r = in" + I + " + item * s" + I + ";\n";
+            assign("r", "    ");
             src += "  }\n";
         }
         for (const Step& s : plan.steps) {
@@ -920,12 +979,39 @@ bool try_fuse(Plan& plan) {
             default: break;
             }
         }
-        src += "  T* o = out + item * so;\n";
-        for (int64_t c = 0; c < plan.out_layout.row_len; ++c)
-            src += "  o[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
-        if (prefetch) src += "  if (nxt >= batch) break;\n  item = nxt;\n  }\n";
+        if (!coalesce) {
+            src += "  T* o = out + item * so;\n";
+            for (int64_t c = 0; c < plan.out_layout.row_len; ++c)
+                src += "  o[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
+        } else {
+            const int plen = padded_len(out_len);
+            const int nch = 64 * out_len / epc;
+            const int per_lane = (nch + 63) / 64;
+            const bool whole = (size_t(out_len) * esz) % 16 == 0;
+            src += std::string("  if (") + (out_via_lds ? "full" : "false") + " && so == " + std::to_string(out_len) + " && (((unsigned long long)out) & 15ull) == 0) {\n";
+            src += "    __syncthreads();\n    T* img = (T*)lds;\n    { T* r = img + lane * " + std::to_string(plen) + ";\n";
+            for (int c = 0; c < out_len; ++c) src += "      r[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
+            src += "    }\n    __syncthreads();\n    VT* dst = (VT*)(out + item0 * " + std::to_string(out_len) + ");\n";
+            for (int j = 0; j < per_lane; ++j) {
+                const bool guard = (j + 1) * 64 > nch;
+                src += std::string("    ") + (guard ? "if (lane + " + std::to_string(64 * j) + " < " + std::to_string(nch) + ") " : "") + "{ const int el = (lane + " +
+                       std::to_string(64 * j) + ") * " + std::to_string(epc) + ";\n      VT c;\n";
+                if (whole) {
+                    src += "      c = *(const VT*)(img + (el / " + std::to_string(out_len) + ") * " + std::to_string(plen) + " + el % " + std::to_string(out_len) + ");\n";
+                } else {
+                    for (int e = 0; e < epc; ++e)
+                        src += "      c[" + std::to_string(e) + "] = img[((el + " + std::to_string(e) + ") / " + std::to_string(out_len) + ") * " + std::to_string(plen) +
+                               " + (el + " + std::to_string(e) + ") % " + std::to_string(out_len) + "];\n";
+                }
+                src += "      dst[lane + " + std::to_string(64 * j) + "] = c;\n    }\n";
+            }
+            src += "  } else if (live) {\n    T* o = out + item * so;\n";
+            for (int64_t c = 0; c < plan.out_layout.row_len; ++c)
+                src += "    o[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
+            src += "  }\n";
+        }
         src += "}\n";
-        f.jit_persistent = prefetch ? 1 : 0;
+        f.jit_threads = threads;
         f.jit_source = std::move(src);
     }
     f.fused_slab = slab;

@@ -67,7 +67,7 @@ struct Step {
     };
     std::vector<FusedInput> fused_inputs;
     int fused_slab = 0, fused_out_base = 0, fused_zero_slot = 0;
-    int jit_persistent = 0;   // the specialised kernel walks items with a grid stride (prefetching): launched on a resident grid
+    int jit_threads = 256;    // workgroup size of the specialised kernel (64: one wave per workgroup, coalesced row I/O through LDS)
     int fused_jit_only = 0;   // the slab is too big for the LDS interpreter: runs only as the hiprtc-specialised kernel
     std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
     void* jit_module = nullptr;

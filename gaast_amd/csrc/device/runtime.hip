@@ -461,11 +461,6 @@ bool jit_compile(Step& s, std::string* log) {
     }
     s.jit_module = mod;
     s.jit_function = fn;
-    if (s.jit_persistent) {  // resident grid of the grid-stride (prefetching) form
-        int per_cu = 0;
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        s.blocks_per_cu = per_cu;
-    }
     return true;
 }
 
@@ -488,10 +483,9 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     args.push_back(&optr);
     args.push_back(&ostride);
     args.push_back(&b);
-    int64_t nblocks = (batch + 255) / 256;
-    if (s.jit_persistent && nblocks > int64_t(g_num_cu) * s.blocks_per_cu) nblocks = int64_t(g_num_cu) * s.blocks_per_cu;
-    const unsigned blocks = unsigned(nblocks);
-    HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, 256, 1, 1, 0, g_stream,
+    const unsigned threads = unsigned(s.jit_threads);
+    const unsigned blocks = unsigned((batch + threads - 1) / threads);
+    HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,
                                   args.data(), nullptr));
     (void)plan;
     return GAAST_OK;

@@ -141,7 +141,8 @@ typedef struct gaast_input_desc {
  * semantics the grade rules imply (grade_set.rs:181-197), see DESIGN.md.  Without the flag such programs report
  * GAAST_ERR_UNIMPLEMENTED exactly where the reference panics. */
 #define GAAST_FLAG_EXP_LOG 0x100u
-#define GAAST_FLAG_NO_PREFETCH 0x200u  /* hiprtc-specialised kernels: one item per lane, no software prefetch (A/B testing) */
+#define GAAST_FLAG_DEBUG_LDS_12K 0x400u /* hiprtc-specialised kernels: 12 KiB instead of 10 KiB of LDS per wave for the row transposition (A/B testing) */
+#define GAAST_FLAG_NO_COALESCE 0x200u  /* hiprtc-specialised kernels: every lane reads / writes its own row (no LDS-transposed coalesced row I/O; A/B testing) */
 
 typedef struct gaast_program_desc {
     int32_t vec_space_dim;      /* n */
