@@ -248,6 +248,12 @@ class SpecializedAst:
             self._out_info = (mask.value, rl.value)
         return self._out_info
 
+    def domain_errors(self):
+        """GAAST_FLAG_EXP_LOG extension: items refused by the exp / log domain check since the last call (synchronises)."""
+        n = C.c_int64()
+        _lib.check(_lib.lib().gaast_hip_program_domain_errors(self.program(), C.byref(n)))
+        return n.value
+
     def jit_source(self):
         """GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE: the HIP source hiprtc compiled for this program."""
         return _lib.lib().gaast_hip_program_jit_source(self.program()).decode()

@@ -54,6 +54,79 @@ __global__ __launch_bounds__(256) void k_scalar_unary(T* __restrict__ res, int64
 }
 
 // ------------------------------------------------------------------------------------------
+// EXTENSION (GAAST_FLAG_EXP_LOG; eval.rs:112-113 is todo!() upstream): res += exp(B) / log(a + B) for a k-vector B whose
+// square is scalar -- the statements of oracle/gaast_oracle.c: ext_exp_log in its order, one thread per item.  Items whose
+// B B has a non-negligible non-scalar part are counted in *dom (gaast_hip_program_domain_errors).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct ExpLogArgs {
+    T* res;
+    const T* arg;
+    int64_t res_stride, arg_stride;
+    int op;                       // 0 exp, 1 log
+    int m, m_res;
+    int arg_k, arg_0, res_k, res_0;   // row offsets, -1 = absent
+    const T* sq;                  // e_i e_i
+    const uint32_t* row_start;    // domain-check rows (n_rows + 1)
+    const uint32_t* pairs;        // i | j << 16
+    const T* pair_coeff;          // 2 e_i e_j
+    int n_rows;
+    unsigned long long* dom;
+    int64_t batch;
+};
+
+__device__ __forceinline__ float sqrt_m(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double sqrt_m(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float sin_m(float x) { return sinf(x); }
+__device__ __forceinline__ double sin_m(double x) { return sin(x); }
+__device__ __forceinline__ float cos_m(float x) { return cosf(x); }
+__device__ __forceinline__ double cos_m(double x) { return cos(x); }
+__device__ __forceinline__ float sinh_m(float x) { return sinhf(x); }
+__device__ __forceinline__ double sinh_m(double x) { return sinh(x); }
+__device__ __forceinline__ float cosh_m(float x) { return coshf(x); }
+__device__ __forceinline__ double cosh_m(double x) { return cosh(x); }
+__device__ __forceinline__ float atan2_m(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double atan2_m(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float atanh_m(float x) { return atanhf(x); }
+__device__ __forceinline__ double atanh_m(double x) { return atanh(x); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_exp_log(ExpLogArgs<T> p) {
+    for (int64_t item = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; item < p.batch; item += int64_t(gridDim.x) * blockDim.x) {
+        const T* B = p.arg + item * p.arg_stride + p.arg_k;
+        T sq = T(0), nrm = T(0), viol = T(0);
+        for (int i = 0; i < p.m; ++i) {
+            sq = sq + B[i] * B[i] * p.sq[i];
+            nrm = nrm + B[i] * B[i];
+        }
+        for (int row = 0; row < p.n_rows; ++row) {
+            T acc = T(0);
+            for (uint32_t e = p.row_start[row]; e < p.row_start[row + 1]; ++e)
+                acc = acc + B[p.pairs[e] & 0xffffu] * B[p.pairs[e] >> 16] * p.pair_coeff[e];
+            viol = viol + acc * acc;
+        }
+        if (p.n_rows > 0 && viol > T(9.094947017729282e-13) * (nrm * nrm)) atomicAdd(p.dom, 1ull);
+        T c0 = T(0), f;
+        if (p.op == 0) {
+            if (sq < T(0)) { const T t = sqrt_m(-sq); c0 = cos_m(t); f = sin_m(t) / t; }
+            else if (sq > T(0)) { const T t = sqrt_m(sq); c0 = cosh_m(t); f = sinh_m(t) / t; }
+            else if (sq == T(0)) { c0 = T(1); f = T(1); }
+            else { c0 = sq; f = sq; }
+        } else {
+            const T a = p.arg_0 >= 0 ? p.arg[item * p.arg_stride + p.arg_0] : T(0);
+            if (sq < T(0)) { const T mm = sqrt_m(-sq); f = atan2_m(mm, a) / mm; }
+            else if (sq > T(0)) { const T mm = sqrt_m(sq); f = atanh_m(mm / a) / mm; }
+            else if (sq == T(0)) { f = T(1) / a; }
+            else { f = sq; }
+        }
+        T* r = p.res + item * p.res_stride;
+        if (p.res_0 >= 0) r[p.res_0] = r[p.res_0] + c0;
+        if (p.res_k >= 0)
+            for (int i = 0; i < p.m_res; ++i) r[p.res_k + i] = r[p.res_k + i] + f * B[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Product arm, exact: the comp-mul list grouped by result component (CSR by output), the
 // entries of one output kept in the reference's order, so every output component sees the
 // very same sequence of roundings as eval.rs:77-83.

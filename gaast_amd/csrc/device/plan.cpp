@@ -194,11 +194,116 @@ struct Lowering {
         case GAAST_OP_PROJ: add_to_res(res, nd.child0); return;  // eval.rs:111
         case GAAST_OP_EXP:
         case GAAST_OP_LOG:  // eval.rs:112-113
+            if (plan.flags & GAAST_FLAG_EXP_LOG) {
+                lower_exp_log(res, id);
+                return;
+            }
             fail(GAAST_ERR_UNIMPLEMENTED, "Exponential / Logarithm evaluation is todo!() in the reference");
             return;
         case GAAST_OP_PRODUCT: lower_product(res, id); return;
         default: throw std::runtime_error("unknown opcode");
         }
+    }
+
+    // EXTENSION (GAAST_FLAG_EXP_LOG; eval.rs:112-113 is todo!() upstream, "no reference behaviour"): the semantics the
+    // reference's grade rules imply (grade_set.rs:181-197), stated in oracle/gaast_oracle.c: ext_exp_log.  The operand is
+    // cached like a product operand (eval.rs:67-68); res += exp / log of it.
+    void lower_exp_log(BufRef res, int id) {
+        const gaast_node_desc& nd = node(id);
+        const bool is_exp = nd.opcode == GAAST_OP_EXP;
+        const gaast_node_desc& ch = node(nd.child0);
+        BufRef arg = store_in_cache(nd.child0);
+        if (!ok()) return;
+        if (key(arg) == key(res)) {
+            fail(GAAST_ERR_MISSING_GRADE, "exp / log operand aliases its own result buffer");
+            return;
+        }
+        int k = -1, nk = 0;
+        for (int g = 0; g < 64; ++g) nk += int((ch.minimal_grade_mask >> g) & 1ULL);
+        for (int g = 0; g < 64; ++g)
+            if (((ch.minimal_grade_mask >> g) & 1ULL) && (g != 0 || (is_exp && nk == 1))) k = g;
+        if (k < 0) {
+            fail(GAAST_ERR_INVALID_PROGRAM, "log can only be used on multivectors of the form <A>_0 + <A>_k");
+            return;
+        }
+        const Layout &la = layout(arg), &lr = layout(res);
+        if (!((la.mask >> k) & 1ULL)) {
+            fail(GAAST_ERR_MISSING_GRADE, "grade absent from exp / log operand");
+            return;
+        }
+        const int dim = ch.vec_space_dim;
+        if (dim != d.vec_space_dim) {
+            fail(GAAST_ERR_INVALID_PROGRAM, "exp / log operand lives in another vector space than the algebra");
+            return;
+        }
+        const int64_t m = la.grade_len(k);
+        Step st;   // filled before emit(): emit invalidates references into plan.steps
+        st.explog_op = is_exp ? 0 : 1;
+        st.explog_m = int(m);
+        st.explog_arg_k = int(la.offset(k));
+        st.explog_arg_0 = (!is_exp && (la.mask & 1ULL) && la.grade_len(0) > 0) ? int(la.offset(0)) : -1;
+        const uint64_t mine = nd.minimal_grade_mask;
+        if (is_exp && (mine & 1ULL)) {
+            if (!(lr.mask & 1ULL)) {
+                fail(GAAST_ERR_MISSING_GRADE, "grade 0 absent from result buffer");
+                return;
+            }
+            st.explog_res_0 = int(lr.offset(0));
+        }
+        if (((mine >> k) & 1ULL) && !(is_exp && k == 0)) {
+            if (!((lr.mask >> k) & 1ULL)) {
+                fail(GAAST_ERR_MISSING_GRADE, "grade " + std::to_string(k) + " absent from result buffer");
+                return;
+            }
+            st.explog_res_k = int(lr.offset(k));
+            st.explog_mres = int(std::min<int64_t>(lr.grade_len(k), m));
+        }
+        // blade squares, and the pairs of commuting blades (the non-scalar part of B B) grouped by product blade
+        std::vector<uint32_t> blade(static_cast<size_t>(m));
+        for (int64_t i = 0; i < m; ++i) blade[size_t(i)] = bt.blade_of[size_t(k)][size_t(i)];
+        st.coeff.resize(size_t(m));
+        for (int64_t i = 0; i < m; ++i)
+            st.coeff[size_t(i)] = blades_gp_coeff(d.vec_space_dim, d.metric_diag, blade[size_t(i)], blade[size_t(i)]);
+        bool structurally_scalar = true;   // every pair of distinct grade-k blades anticommutes
+        for (int64_t i = 0; i < m && structurally_scalar; ++i)
+            for (int64_t j = i + 1; j < m; ++j)
+                if (((k - __builtin_popcount(blade[size_t(i)] & blade[size_t(j)])) & 1) == 0) {
+                    structurally_scalar = false;
+                    break;
+                }
+        st.u32_a.assign(1, 0u);
+        if (!structurally_scalar) {
+            if (m > 512) {
+                if (plan.unsupported.empty())
+                    plan.unsupported = "exp / log of a " + std::to_string(m) + "-component k-vector: the domain check (square is scalar) is built for up to 512 components";
+                return;
+            }
+            std::map<uint64_t, std::vector<std::pair<uint32_t, double>>> rows;   // T -> (i | j << 16, 2 e_i e_j), in (i, j) order
+            for (int64_t i = 0; i < m; ++i)
+                for (int64_t j = i + 1; j < m; ++j) {
+                    const double c1 = blades_gp_coeff(d.vec_space_dim, d.metric_diag, blade[size_t(i)], blade[size_t(j)]);
+                    const double c2 = blades_gp_coeff(d.vec_space_dim, d.metric_diag, blade[size_t(j)], blade[size_t(i)]);
+                    if (c1 == c2) rows[uint64_t(blade[size_t(i)] ^ blade[size_t(j)])].push_back({uint32_t(i) | (uint32_t(j) << 16), 2.0 * c1});
+                }
+            for (auto& kv : rows) {
+                for (auto& e : kv.second) {
+                    st.u32_c.push_back(e.first);
+                    st.coeff_b.push_back(e.second);
+                }
+                st.u32_a.push_back(uint32_t(st.u32_c.size()));
+            }
+        }
+        Step& s = emit(Step::EXPLOG, res, std::string(is_exp ? "exponential" : "logarithm") + "[grade " + std::to_string(k) + ", " +
+                                              std::to_string(m) + " components, " + std::to_string(st.u32_c.size()) + " domain-check pairs]");
+        const BufRef keep_res = s.res;
+        const std::string keep_name = s.name;
+        s = std::move(st);
+        s.kind = Step::EXPLOG;
+        s.res = keep_res;
+        s.name = keep_name;
+        s.a = arg;
+        plan.has_explog = 1;
+        touch(res);
     }
 
     // Which buffer a Product reads for operand `id`.  Exact rewrites (off with NO_FUSION):
@@ -680,7 +785,8 @@ bool try_fuse(Plan& plan) {
     // the LDS interpreter kernel needs the slabs of 64 items in 48 KiB; the hiprtc-specialised kernel keeps the slab
     // in registers and only needs it to be small enough for that -- plans that fit only the latter are fused
     // "JIT only" (the runtime falls back to an unfused plan if the compilation fails)
-    const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024);
+    // (plans with exp / log steps have no interpreter micro-ops: the specialised kernel or nothing)
+    const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024) && !plan.has_explog;
     const int jit_slab_limit = plan.dtype == GAAST_F32 ? 200 : 160;
     const bool jit_allowed = !(plan.flags & GAAST_FLAG_NO_JIT) && slab <= jit_slab_limit;
     if (!interp_ok && !jit_allowed) return false;
@@ -802,6 +908,7 @@ bool try_fuse(Plan& plan) {
             }
             break;
         }
+        case Step::EXPLOG: break;   // specialised kernel only (interp_ok is false)
         default: return false;
         }
         for (int g = 0; g < G; ++g) {
@@ -873,7 +980,7 @@ bool try_fuse(Plan& plan) {
         src += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ") void gaast_jit(";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i)
             src += "const T* __restrict__ in" + std::to_string(i) + ", long long s" + std::to_string(i) + ", ";
-        src += "T* __restrict__ out, long long so, long long batch) {\n";
+        src += std::string("T* __restrict__ out, long long so, long long batch") + (plan.has_explog ? ", unsigned long long* dom" : "") + ") {\n";
         if (coalesce) {
             src += "  __shared__ __attribute__((aligned(16))) unsigned char lds[" + std::to_string(lds_total) + "];\n";
             src += "  const int lane = threadIdx.x;\n  const long long item0 = blockIdx.x * 64LL;\n";
@@ -955,6 +1062,47 @@ bool try_fuse(Plan& plan) {
                     src += "  " + d + " = T(1) / " + d + ";\n";
                 else
                     src += "  " + d + (plan.dtype == GAAST_F32 ? " = __builtin_sqrtf(" : " = __builtin_sqrt(") + d + ");\n";
+                break;
+            }
+            case Step::EXPLOG: {   // the statements of oracle/gaast_oracle.c: ext_exp_log, in its order
+                const uint32_t ab = uint32_t(base_of(s.a));
+                const bool f32 = plan.dtype == GAAST_F32;
+                auto fn = [&](const char* name) { return std::string(name) + (f32 ? "f" : ""); };
+                auto B = [&](uint32_t i) { return var(ab + uint32_t(s.explog_arg_k) + i); };
+                src += "  { T sq = T(0), nrm = T(0), viol = T(0);\n";
+                for (int i = 0; i < s.explog_m; ++i) {
+                    src += "    sq = sq + " + B(uint32_t(i)) + " * " + B(uint32_t(i)) + " * T(" + lit(s.coeff[size_t(i)]) + ");\n";
+                    src += "    nrm = nrm + " + B(uint32_t(i)) + " * " + B(uint32_t(i)) + ";\n";
+                }
+                for (size_t row = 0; row + 1 < s.u32_a.size(); ++row) {
+                    src += "    { T acc = T(0);\n";
+                    for (uint32_t e = s.u32_a[row]; e < s.u32_a[row + 1]; ++e)
+                        src += "      acc = acc + " + B(s.u32_c[e] & 0xffffu) + " * " + B(s.u32_c[e] >> 16) + " * T(" + lit(s.coeff_b[e]) + ");\n";
+                    src += "      viol = viol + acc * acc; }\n";
+                }
+                if (s.u32_a.size() > 1)
+                    src += std::string("    if (viol > T(") + lit(9.094947017729282e-13) + ") * (nrm * nrm)) atomicAdd(dom, 1ull);\n";
+                src += "    T c0 = T(0), f;\n";
+                if (s.explog_op == 0) {
+                    src += "    if (sq < T(0)) { const T t = " + fn("sqrt") + "(-sq); c0 = " + fn("cos") + "(t); f = " + fn("sin") + "(t) / t; }\n";
+                    src += "    else if (sq > T(0)) { const T t = " + fn("sqrt") + "(sq); c0 = " + fn("cosh") + "(t); f = " + fn("sinh") + "(t) / t; }\n";
+                    src += "    else if (sq == T(0)) { c0 = T(1); f = T(1); }\n    else { c0 = sq; f = sq; }\n";
+                } else {
+                    const std::string a = s.explog_arg_0 >= 0 ? var(ab + uint32_t(s.explog_arg_0)) : std::string("T(0)");
+                    src += "    if (sq < T(0)) { const T mm = " + fn("sqrt") + "(-sq); f = " + fn("atan2") + "(mm, " + a + ") / mm; }\n";
+                    src += "    else if (sq > T(0)) { const T mm = " + fn("sqrt") + "(sq); f = " + fn("atanh") + "(mm / " + a + ") / mm; }\n";
+                    src += "    else if (sq == T(0)) { f = T(1) / " + a + "; }\n    else { f = sq; }\n";
+                }
+                if (s.explog_res_0 >= 0) {
+                    const std::string d = var(rb + uint32_t(s.explog_res_0));
+                    src += "    " + d + " = " + d + " + c0;\n";
+                }
+                if (s.explog_res_k >= 0)
+                    for (int i = 0; i < s.explog_mres; ++i) {
+                        const std::string d = var(rb + uint32_t(s.explog_res_k) + uint32_t(i));
+                        src += "    " + d + " = " + d + " + f * " + B(uint32_t(i)) + ";\n";
+                    }
+                src += "  }\n";
                 break;
             }
             case Step::PRODUCT_CSR: {

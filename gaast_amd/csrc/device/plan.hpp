@@ -35,7 +35,7 @@ inline Layout make_layout(int dim, uint64_t mask) {
 }
 
 struct Step {
-    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED } kind = ZERO;
+    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG } kind = ZERO;
     BufRef res, a, b;
     std::string name;
     // host images of the tables (uploaded once at program_create)
@@ -46,6 +46,16 @@ struct Step {
     std::vector<double> coeff_host; // FUSED: the general coefficients, passed by value at launch
     std::vector<int32_t> i32_a;    // DENSE out_map
     int sunary_op = 0, sunary_off = 0;
+    // EXPLOG (GAAST_FLAG_EXP_LOG extension): res += exp(arg) / log(arg), arg = buffer `a` holding a k-vector (log: + grade 0).
+    //   coeff[i] = e_i e_i (blade squares, component order); pairs of distinct blades that commute, grouped by the blade T of
+    //   their product in ascending T: u32_a = row starts, u32_c = i | j << 16, coeff_b = 2 e_i e_j -- the domain check.
+    int explog_op = 0;                       // 0 exp, 1 log
+    int explog_m = 0, explog_mres = 0;       // components of the k-vector / of them that res holds (zip)
+    int explog_arg_k = 0, explog_arg_0 = -1; // offsets in the operand row (grade k; grade 0 for log, -1 = absent)
+    int explog_res_k = -1, explog_res_0 = -1;// offsets in the result row, -1 = not produced
+    std::vector<double> coeff_b;
+    void* d_coeff_b = nullptr;
+    void* d_domain = nullptr;                // the program's domain-error counter (device, not owned by the step)
     int ell_bytes = 0;             // ... and the offsets of its entries are byte offsets
     int ell_width = 0;             // PRODUCT_CSR with rows of one length and +-1 coefficients: u32_c is [term][row], sign in bit 31
     int canon_a = 0, canon_b = 0;
@@ -106,6 +116,7 @@ struct Plan {
     std::vector<Step> steps;
     int error = GAAST_OK;              // what the reference would have panicked with, at eval
     std::string error_msg;
+    int has_explog = 0;                // some step evaluates exp / log: the program owns a domain-error counter
     std::string unsupported;           // non-empty: valid in the reference, beyond this back end (program_create fails)
     std::vector<char> slot_used;       // input slots some launch reads (the others may stay unbound)
     std::string jit_source_kept;       // GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE

@@ -81,11 +81,13 @@ struct gaast_hip_program_s {
     std::vector<gaast_hip_mv_t> scratch;    // per node buffer, sized for scratch_batch
     int64_t scratch_batch = 0;
     std::vector<std::string> launch_names;
+    void* d_domain = nullptr;               // exp / log extension: items refused by the domain check (unsigned long long)
     gaast_hip_program_s() = default;
     gaast_hip_program_s(const gaast_hip_program_s&) = delete;
     gaast_hip_program_s& operator=(const gaast_hip_program_s&) = delete;
     ~gaast_hip_program_s() {  // every failure path of program_create and program_destroy end here
         release_plan_resources(plan);
+        if (d_domain) (void)hipFree(d_domain);
         for (gaast_hip_mv_t m : const_mvs) mv_free_impl(m);
         for (gaast_hip_mv_t m : scratch) mv_free_impl(m);
     }
@@ -96,7 +98,7 @@ namespace {
 // device tables and hiprtc modules of a plan (also called before a plan is rebuilt)
 void release_plan_resources(Plan& plan) {
     for (Step& s : plan.steps) {
-        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32}) {
+        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -306,6 +308,29 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         hipLaunchKernelGGL(k_scalar_unary<T>, dim3(grid_for(batch, 256)), dim3(256), 0, g_stream,
                            static_cast<T*>(res.ptr), res.stride, s.sunary_off, s.sunary_op, batch);
         break;
+    case Step::EXPLOG: {
+        ExpLogArgs<T> q;
+        q.res = static_cast<T*>(res.ptr);
+        q.arg = static_cast<const T*>(a.ptr);
+        q.res_stride = res.stride;
+        q.arg_stride = a.stride;
+        q.op = s.explog_op;
+        q.m = s.explog_m;
+        q.m_res = s.explog_mres;
+        q.arg_k = s.explog_arg_k;
+        q.arg_0 = s.explog_arg_0;
+        q.res_k = s.explog_res_k;
+        q.res_0 = s.explog_res_0;
+        q.sq = static_cast<const T*>(s.d_coeff);
+        q.row_start = static_cast<const uint32_t*>(s.d_a);
+        q.pairs = static_cast<const uint32_t*>(s.d_c);
+        q.pair_coeff = static_cast<const T*>(s.d_coeff_b);
+        q.n_rows = int(s.u32_a.size()) - 1;
+        q.dom = static_cast<unsigned long long*>(s.d_domain);
+        q.batch = batch;
+        hipLaunchKernelGGL(k_exp_log<T>, dim3(grid_for(batch, 256)), dim3(256), 0, g_stream, q);
+        break;
+    }
     case Step::PRODUCT_CSR: {
         if (s.ell_width > 0) {
             EllArgs<T> q;
@@ -483,6 +508,8 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     args.push_back(&optr);
     args.push_back(&ostride);
     args.push_back(&b);
+    void* dom = s.d_domain;
+    if (plan.has_explog) args.push_back(&dom);
     const unsigned threads = unsigned(s.jit_threads);
     const unsigned blocks = unsigned((batch + threads - 1) / threads);
     HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,
@@ -632,7 +659,12 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         }
     };
     plan.slot_used.assign(plan.inputs.size(), 0);
+    if (plan.has_explog) {
+        HIP_TRY(hipMalloc(&prog->d_domain, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(prog->d_domain, 0, sizeof(unsigned long long)));
+    }
     for (Step& s : plan.steps) {
+        s.d_domain = prog->d_domain;
         // kernel choice, LDS budget, persistent grid: fixed here, and a program no kernel can run is refused whole
         const Layout la = layout_of(s.a), lb = layout_of(s.b);
         if (int st = plan.dtype == GAAST_F32 ? prepare_step<float>(s, la, lb, plan.n) : prepare_step<double>(s, la, lb, plan.n))
@@ -650,6 +682,14 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
                 if (int st = upload_vec(cf, &s.d_coeff)) return st;
             } else {
                 if (int st = upload_vec(s.coeff, &s.d_coeff)) return st;
+            }
+        }
+        if (!s.coeff_b.empty()) {
+            if (plan.dtype == GAAST_F32) {
+                std::vector<float> cf(s.coeff_b.begin(), s.coeff_b.end());
+                if (int st = upload_vec(cf, &s.d_coeff_b)) return st;
+            } else {
+                if (int st = upload_vec(s.coeff_b, &s.d_coeff_b)) return st;
             }
         }
         // the host images of the big tables are no longer needed
@@ -683,6 +723,19 @@ int gaast_hip_program_destroy(gaast_hip_program_t prog) {
     if (!prog) return GAAST_OK;
     if (g_init) (void)hipSetDevice(g_device);
     delete prog;
+    return GAAST_OK;
+}
+
+int gaast_hip_program_domain_errors(gaast_hip_program_t prog, int64_t* count) {
+    if (!prog || !count) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
+    if (int st = ensure_init()) return st;
+    *count = 0;
+    if (!prog->d_domain) return GAAST_OK;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, prog->d_domain, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(prog->d_domain, 0, sizeof(v)));
+    *count = int64_t(v);
     return GAAST_OK;
 }
 

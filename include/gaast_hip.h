@@ -178,6 +178,10 @@ int gaast_hip_program_output_info(gaast_hip_program_t prog, uint64_t *grade_mask
 /* number of kernel launches one eval issues, and a one-line description of launch `i` */
 int gaast_hip_program_num_launches(gaast_hip_program_t prog);
 const char *gaast_hip_program_launch_name(gaast_hip_program_t prog, int i);
+/* GAAST_FLAG_EXP_LOG extension: how many items, since the last call, had an exp / log operand outside the domain (a
+ * k-vector whose square is not scalar: |<B B>_{not 0}|^2 > 2^-40 (sum B_i^2)^2); their results are the closed form applied
+ * to <B B>_0 regardless.  Synchronises the library stream; resets the counter.  0 for programs without exp / log. */
+int gaast_hip_program_domain_errors(gaast_hip_program_t prog, int64_t *count);
 /* GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE: the HIP source generated for this program ("" if none). */
 const char *gaast_hip_program_jit_source(gaast_hip_program_t prog);
 

@@ -562,6 +562,7 @@ typedef struct gnode {
 } gnode;
 
 struct og_spec {
+    og_algebra alg; /* the algebra given to specialize (the EXTENSION arms need blade squares at eval time) */
     gnode *nodes; /* NodeArena (a HashMap in the reference; order is irrelevant) */
     int n_nodes, cap_nodes;
     int root;
@@ -916,6 +917,7 @@ og_spec *og_specialize(og_expr *e, const og_algebra *alg, int *status) { /* spec
     int st = OG_OK;
     og_spec *s = (og_spec *)calloc(1, sizeof(og_spec));
     s->root_expr = og_expr_retain(e);
+    s->alg = *alg;
     builder b = {alg, s, OG_OK};
     og_gradeset root_gs;
     /* Expr::reify, expr.rs:62-69 */
@@ -1028,6 +1030,129 @@ static void store_in_cache(const og_spec *s, int this_id, cache *c) { /* eval.rs
     }
 }
 
+/*
+ * EXTENSION -- "no reference behaviour, parity unpinned".  eval.rs:112-113 is todo!(); what IS pinned by the reference
+ * are the grade rules: exp takes a single-grade k-vector to grades {0, k} (grade_set.rs:181-188), log takes
+ * <A>_0 + <A>_k to grade {k} (grade_set.rs:190-197), and minimal sets flow down as wanted.log() / wanted.exp()
+ * (specialize.rs:91-92).  Those rules only make sense for a k-vector B whose square is a scalar, s = <B B>_0; then
+ *     exp(B) = cos(t) + B sin(t)/t,  t = sqrt(-s)   (s < 0)        log(a + B)|_k = B atan2(m, a) / m,  m = sqrt(-s)
+ *            = cosh(t) + B sinh(t)/t, t = sqrt(s)    (s > 0)                      = B atanh(m / a) / m, m = sqrt(s)
+ *            = 1 + B                                 (s == 0)                     = B / a
+ * (the logarithm's scalar part, ln|A|, has no grade to go to: log is the versor logarithm, exact for unit versors, and
+ * pow = exp(log * p), expr.rs:300-303, is the power of the normalised versor).
+ * The operand is evaluated into its own buffer like a product operand (eval.rs:67-68) and the result is ADDED to res
+ * (like every arm).  s = sum_i (B_i * B_i) * sq_i in component order, sq_i = e_i e_i from ortho_basis_blades_gp
+ * (algebra.rs:73-83), each term rounded like eval.rs:82.  Domain: B is refused (OG_PANIC_DOMAIN) when the non-scalar
+ * part of B B is not negligible, sum_T (<B B>_T)^2 > 2^-40 (sum_i B_i^2)^2.
+ */
+static void ext_exp_log(const og_spec *s, int res_id, int this_id, cache *c) {
+    const gnode *this_ = &s->nodes[this_id];
+    const int is_exp = this_->kind == OG_N_EXPONENTIAL;
+    store_in_cache(s, this_->child0, c);
+    if (c->status != OG_OK) return;
+    og_mv *res = c->slot[res_id];
+    og_mv *arg = c->slot[this_->child0];
+    if (res == arg) {
+        set_panic("exp / log operand aliases its own result buffer");
+        c->status = OG_PANIC_MISSING_GRADE;
+        return;
+    }
+    /* the k-vector part: the one non-zero grade of the operand's minimal set (exp: the only grade) */
+    const gnode *child = &s->nodes[this_->child0];
+    int ks[OG_MAX_GRADE];
+    int nk = og_gs_iter(child->minimal, ks, OG_MAX_GRADE);
+    int k = -1;
+    for (int t = 0; t < nk; ++t)
+        if (ks[t] != 0 || (is_exp && nk == 1)) k = ks[t];
+    if (k < 0) { /* log of a bare scalar: grade_set.rs:192-195 already refuses it while the Expr is built */
+        set_panic("log can only be used on multivectors of the form <A>_0 + <A>_k");
+        c->status = OG_PANIC_ASSERT;
+        return;
+    }
+    if (!((arg->mask >> k) & 1ULL)) {
+        set_panic("grade absent from exp / log operand");
+        c->status = OG_PANIC_MISSING_GRADE;
+        return;
+    }
+    const double *B = arg->slab[k];
+    const size_t m = arg->len[k];
+    const int dim = child->vec_space_dim;
+    double sq = 0.0, nrm = 0.0;
+    uint64_t *blade = (uint64_t *)malloc((m ? m : 1) * sizeof(uint64_t));
+    for (size_t i = 0; i < m; ++i) {
+        uint64_t r;
+        blade[i] = og_index_to_bitfield_permut(dim, k, i);
+        const double sqi = og_ortho_basis_blades_gp(&s->alg, blade[i], blade[i], &r);
+        sq += B[i] * B[i] * sqi;
+        nrm += B[i] * B[i];
+    }
+    /* non-scalar part of B B: pairs of distinct blades that commute contribute 2 B_i B_j e_i e_j */
+    double viol = 0.0;
+    {
+        const size_t nblades = (size_t)1 << dim;
+        double *acc = (double *)calloc(nblades, sizeof(double));
+        for (size_t i = 0; i < m; ++i)
+            for (size_t j = i + 1; j < m; ++j) {
+                uint64_t r1, r2;
+                const double c1 = og_ortho_basis_blades_gp(&s->alg, blade[i], blade[j], &r1);
+                const double c2 = og_ortho_basis_blades_gp(&s->alg, blade[j], blade[i], &r2);
+                if (c1 == c2) acc[r1] += B[i] * B[j] * (2.0 * c1); /* they commute (else c1 == -c2 and the pair cancels) */
+            }
+        for (size_t t = 0; t < nblades; ++t) viol += acc[t] * acc[t];
+        free(acc);
+    }
+    free(blade);
+    if (viol > OG_EXPLOG_DOMAIN_TOL2 * (nrm * nrm)) {
+        set_panic("exp / log of a k-vector whose square is not a scalar");
+        c->status = OG_PANIC_DOMAIN;
+        return;
+    }
+    double c0 = 0.0, f;
+    if (is_exp) {
+        if (sq < 0.0) {
+            const double t = sqrt(-sq);
+            c0 = cos(t);
+            f = sin(t) / t;
+        } else if (sq > 0.0) {
+            const double t = sqrt(sq);
+            c0 = cosh(t);
+            f = sinh(t) / t;
+        } else if (sq == 0.0) {
+            c0 = 1.0;
+            f = 1.0;
+        } else {
+            c0 = sq; /* NaN propagates */
+            f = sq;
+        }
+    } else {
+        double a = 0.0;
+        if ((arg->mask & 1ULL) && arg->len[0] > 0) a = arg->slab[0][0];
+        if (sq < 0.0) {
+            const double mm = sqrt(-sq);
+            f = atan2(mm, a) / mm;
+        } else if (sq > 0.0) {
+            const double mm = sqrt(sq);
+            f = atanh(mm / a) / mm;
+        } else if (sq == 0.0) {
+            f = 1.0 / a;
+        } else {
+            f = sq;
+        }
+    }
+    og_gradeset mine = this_->minimal;
+    if (is_exp && og_gs_contains(mine, 0)) {
+        double *r0 = grade_slice_mut(res, 0, &c->status);
+        if (!r0) return;
+        r0[0] = r0[0] + c0;
+    }
+    if (og_gs_contains(mine, k) && !(is_exp && k == 0)) {
+        double *rk = grade_slice_mut(res, (size_t)k, &c->status);
+        if (!rk) return;
+        const size_t len = res->len[k] < m ? res->len[k] : m;
+        for (size_t i = 0; i < len; ++i) rk[i] = rk[i] + f * B[i];
+    }
+}
+
 static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /* eval.rs:35-115 */
     if (c->status != OG_OK) return;
     const gnode *this_ = &s->nodes[this_id];
@@ -1087,7 +1212,7 @@ static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /*
         nk = og_gs_iter(this_->minimal, ks, OG_MAX_GRADE);
         for (int t = 0; t < nk; ++t) {
             size_t k = (size_t)ks[t];
-            if (k == 0 && c->mode == OG_EVAL_DEBUG) { /* `k - 1` on usize, overflow checks on */
+            if (k == 0 && (c->mode & OG_EVAL_DEBUG)) { /* `k - 1` on usize, overflow checks on */
                 set_panic("attempt to subtract with overflow");
                 c->status = OG_PANIC_OVERFLOW;
                 return;
@@ -1118,6 +1243,10 @@ static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /*
         return;
     case OG_N_EXPONENTIAL:
     case OG_N_LOGARITHM: /* eval.rs:112-113 */
+        if (c->mode & OG_EVAL_EXT_EXPLOG) {
+            ext_exp_log(s, res_id, this_id, c);
+            return;
+        }
         set_panic("not yet implemented");
         c->status = OG_PANIC_TODO;
         return;

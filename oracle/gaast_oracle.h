@@ -37,6 +37,7 @@ enum {
     OG_PANIC_TODO = 2,          /* eval.rs:112-113 todo!() for Exponential / Logarithm */
     OG_PANIC_ASSERT = 3,        /* grade_set.rs:182-195, specialize.rs:104-117 asserts */
     OG_PANIC_OVERFLOW = 4,      /* eval.rs:90 `k - 1` on usize with k == 0 (debug builds only) */
+    OG_PANIC_DOMAIN = 5,        /* EXTENSION (no reference behaviour): exp / log of a k-vector whose square is not scalar */
     OG_BAD_ARG = 5
 };
 
@@ -163,7 +164,13 @@ const og_comp_mul *og_spec_comp_muls(const og_spec *s, int idx);
 
 /* ---- SpecializedAst::eval::<GradeMapMV>() (eval.rs:12-115) ---- */
 enum { OG_EVAL_RELEASE = 0, /* k*(k-1)/2 wraps for k == 0: grade 0 untouched */
-       OG_EVAL_DEBUG = 1 }; /* overflow checks on: Reverse over grade 0 panics */
+       OG_EVAL_DEBUG = 1,   /* overflow checks on: Reverse over grade 0 panics */
+       /* EXTENSION, bit flag, "no reference behaviour, parity unpinned": evaluate Exponential / Logarithm (todo!() in
+        * eval.rs:112-113) with the semantics the reference's grade rules imply (grade_set.rs:181-197), see the
+        * comment above ext_exp_log() in gaast_oracle.c.  Without the flag these arms panic like the reference. */
+       OG_EVAL_EXT_EXPLOG = 2 };
+/* tolerance of the extension's domain check: a k-vector B is accepted when |<B^2>_{not 0}|^2 <= 2^-40 (sum B_i^2)^2 */
+#define OG_EXPLOG_DOMAIN_TOL2 9.094947017729282e-13
 int og_eval(const og_spec *s, int mode, og_mv **out);
 
 /*

@@ -241,6 +241,16 @@ int main() {
         lower(gaast_expr_sub(gaast_expr_ginvol(a), gaast_expr_neg(gaast_expr_rev(b))), 4, euclid, GAAST_F64, 0, "unary chain", nullptr);
         lower(gaast_expr_vinv(gaast_expr_input(2, 0x2, 4)), 4, euclid, GAAST_F64, 0, "vinv", nullptr);
     }
+    {   // exp / log extension: the step's tables (blade squares, commuting pairs) for simple and non-simple grades
+        gaast_expr_t b = gaast_expr_input(0, 0x4, 5), x = gaast_expr_input(1, 0x2, 5);
+        gaast_expr_t r = H(gaast_expr_exp(b));
+        gaast_expr_t sw = gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC);
+        lower(sw, 5, cga, GAAST_F64, GAAST_FLAG_EXP_LOG, "exp(B) x ~exp(B), fused", "ast_");
+        lower(sw, 5, cga, GAAST_F64, GAAST_FLAG_EXP_LOG | GAAST_FLAG_NO_FUSION, "exp(B) x ~exp(B), unfused", "exponential[grade 2, 10 components, 15 domain-check pairs]");
+        lower(H(gaast_expr_log(r)), 5, cga, GAAST_F32, GAAST_FLAG_EXP_LOG | GAAST_FLAG_NO_FUSION, "log(exp(B))", "logarithm[grade 2");
+        lower(H(gaast_expr_exp(gaast_expr_input(2, 0x2, 4))), 4, euclid, GAAST_F64, GAAST_FLAG_EXP_LOG | GAAST_FLAG_NO_FUSION, "exp(vector)", "0 domain-check pairs");
+        lower(sw, 5, cga, GAAST_F64, 0, "exp without the flag: plan records UNIMPLEMENTED", nullptr);
+    }
     {   // dense tables under a basis permutation == the reference's list, for every kernel's table format
         const double pga6[6] = {0, 1, 1, 1, 1, -1}, anti6[6] = {-1, 1, -1, -1, -1, 1}, sta6[6] = {-1, 1, 1, 1, 0, 1};
         dense_tables_agree_with_the_list(6, euclid, GAAST_F64, 0, "dense tables n=6 euclid", "product_dense[gp n=6]");

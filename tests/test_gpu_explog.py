@@ -1,0 +1,119 @@
+"""exp / log on the GPU (GAAST_FLAG_EXP_LOG) against the oracle's extension (OG_EVAL_EXT_EXPLOG).  "No reference behaviour,
+parity unpinned": upstream eval.rs:112-113 is todo!(); both sides implement the semantics the reference's grade rules imply
+(oracle/gaast_oracle.c: ext_exp_log) with the same statements in the same order, so the only differences are the last bits
+of the device's sin / cos / sinh / cosh / atan2 / atanh against glibc's.  Tolerance: 8 eps of the row's largest
+magnitude (eps of the program's dtype).  Without the flag the status stays UNIMPLEMENTED (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+import gaast_amd as ga
+from helpers import hip_eval_batch, oracle_eval_batch
+from oracle import pyoracle as og
+
+pytestmark = pytest.mark.gpu
+EXT = og.EVAL_EXT_EXPLOG
+CGA = [1.0, 1.0, 1.0, 1.0, -1.0]
+STA = [1.0, -1.0, -1.0, -1.0]
+ALGS = {"r3": 3, "cga": CGA, "sta": STA}
+
+
+def _dim(alg):
+    return alg if isinstance(alg, int) else len(alg)
+
+
+def _wedge_rows(n, batch, rng, scale=1.0):
+    """rows of simple bivectors u ^ v, components in the reference's (colex) order"""
+    u, v = rng.uniform(-1, 1, (batch, n)), rng.uniform(-1, 1, (batch, n))
+    cols = [(i, j) for j in range(n) for i in range(j)]
+    return scale * np.stack([u[:, i] * v[:, j] - u[:, j] * v[:, i] for i, j in cols], axis=1)
+
+
+def _check(build, alg, rows, batch, dtype=ga.F64, flags=0, expect_kernel=None):
+    want, wmask = oracle_eval_batch(build, alg, rows, batch, mode=EXT)
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    got, mask, spec = hip_eval_batch(build, alg, {s: r.astype(npdt) for s, r in rows.items()}, batch, dtype=dtype,
+                                     flags=ga.FLAG_EXP_LOG | flags)
+    assert mask == wmask
+    if expect_kernel:
+        assert any(expect_kernel in l for l in spec.launches()), spec.launches()
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+    scale = np.maximum(1.0, np.abs(want).max(axis=1, keepdims=True))
+    # f32 programs also carry the rounding of the inputs and of every f32 operation of the closed form
+    tol = (64 if dtype == ga.F32 else 8) * eps * scale
+    assert np.all(np.abs(got.astype(np.float64) - want) <= tol), float((np.abs(got - want) / tol).max())
+    assert spec.domain_errors() == 0
+    return spec
+
+
+@pytest.mark.parametrize("name", sorted(ALGS))
+@pytest.mark.parametrize("flags,kernel", [(0, "ast_jit"), (ga.FLAG_NO_FUSION, "exponential"), (ga.FLAG_DEBUG_JIT_FAILS, "exponential")])
+def test_exp_of_a_simple_bivector(name, flags, kernel):
+    alg = ALGS[name]
+    n, batch = _dim(alg), 257
+    rows = {0: _wedge_rows(n, batch, np.random.default_rng(1), 1.2)}
+    _check(lambda B: B.input(0, [2], n).exp(), alg, rows, batch, flags=flags, expect_kernel=kernel)
+
+
+@pytest.mark.parametrize("name", sorted(ALGS))
+def test_rotor_from_its_generator_and_back(name):
+    """log(exp(B)), exp(log(R)) and the sandwich exp(B) x ~exp(B) in one launch"""
+    alg = ALGS[name]
+    n, batch = _dim(alg), 300
+    rng = np.random.default_rng(2)
+    rows = {0: _wedge_rows(n, batch, rng, 0.6), 1: rng.uniform(-1, 1, (batch, n))}
+    _check(lambda B: B.input(0, [2], n).exp().log(), alg, rows, batch, expect_kernel="ast_jit")
+    _check(lambda B: B.input(0, [2], n).exp().log().exp(), alg, rows, batch)
+
+    def sandwich(B):
+        r = B.input(0, [2], n).exp()
+        return (r * B.input(1, [1], n) * r.rev()).g(1)
+    spec = _check(sandwich, alg, rows, batch, expect_kernel="ast_jit")
+    assert len(spec.launches()) == 1
+
+
+def test_pow_and_sqrt_of_a_rotor():
+    """expr.rs:300-319: pow = exp(log * p); sqrt of a non-scalar = pow(0.5)"""
+    n, batch = 3, 100
+    rows = {0: _wedge_rows(n, batch, np.random.default_rng(3), 0.9)}
+    _check(lambda B: B.input(0, [2], n).exp().sqrt(), 3, rows, batch)
+    _check(lambda B: B.input(0, [2], n).exp().pow(B.scalar(3.0)), 3, rows, batch)
+
+
+def test_exp_log_in_f32_and_unfused_log():
+    n, batch = 5, 129
+    rows = {0: _wedge_rows(n, batch, np.random.default_rng(4), 0.8)}
+    _check(lambda B: B.input(0, [2], n).exp(), CGA, rows, batch, dtype=ga.F32)
+    _check(lambda B: B.input(0, [2], n).exp().log(), CGA, rows, batch, flags=ga.FLAG_NO_FUSION, expect_kernel="logarithm")
+
+
+def test_vectors_and_pseudoscalars_need_no_domain_check():
+    """grade 1 and grade n are structurally simple: no pair list, exp(v) = cosh|v| + v sinh|v| / |v| in R^3"""
+    rng = np.random.default_rng(5)
+    rows = {0: rng.uniform(-1, 1, (50, 3))}
+    spec = _check(lambda B: B.input(0, [1], 3).exp(), 3, rows, 50)
+    assert "0 domain-check pairs" in spec.launches()[0] or "ast_jit" in spec.launches()[0]
+    rows = {0: rng.uniform(-1, 1, (50, 1))}
+    _check(lambda B: B.input(0, [3], 3).exp(), 3, rows, 50)
+
+
+@pytest.mark.parametrize("flags", [0, ga.FLAG_NO_FUSION])
+def test_bivectors_whose_square_is_not_scalar_are_counted(flags):
+    """R^4: e12 + e34 squares to -2 + 2 e1234.  The oracle refuses such an item (OG_PANIC_DOMAIN); the device counts it
+    (gaast_hip_program_domain_errors) and the other items of the batch are unaffected."""
+    n, batch = 4, 64
+    rng = np.random.default_rng(6)
+    rows = _wedge_rows(n, batch, rng, 1.0)
+    bad = [3, 17, 40]
+    for i in bad:
+        rows[i] = [1.0, 0.0, 0.0, 0.0, 0.0, 0.7]
+    build = lambda B: B.input(0, [2], n).exp()
+    got, _, spec = hip_eval_batch(build, n, {0: rows}, batch, flags=ga.FLAG_EXP_LOG | flags)
+    assert spec.domain_errors() == len(bad)
+    assert spec.domain_errors() == 0                     # the counter resets
+    good = [i for i in range(batch) if i not in bad]
+    want, _ = oracle_eval_batch(build, n, {0: rows[good]}, len(good), mode=EXT)
+    assert np.all(np.abs(got[good] - want) <= 8 * 2.0 ** -52 * np.maximum(1.0, np.abs(want).max(axis=1, keepdims=True)))
+    for i in bad:
+        with pytest.raises(og.OraclePanic) as ei:
+            oracle_eval_batch(build, n, {0: rows[i:i + 1]}, 1, mode=EXT)
+        assert ei.value.code == og.PANIC_DOMAIN
