@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
+GATHER_WATCHDOG_S = 240     # the multi-GPU gather legs give up after this long (the throughput line is printed regardless)
 
 
 def workload_spec(name):
@@ -282,6 +283,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     rccl_ranks = None
     lib_comm = False
+    lib_comm_error = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -300,17 +302,35 @@ def main():
         if not rehearsal:
             # the library's own communicator (what a Rust host would use: include/gaast_hip.h, multi-GPU): the
             # 128-byte id travels over the rendezvous torch.distributed already provides
+            # (a failure here is reported in the JSON and the gather falls back to torch.distributed: the throughput
+            # line must not depend on it)
             idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)()
+            ok = 1
             if rank == 0:
-                ga._lib.check(L.gaast_hip_comm_unique_id(idbuf))
-            idt = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+                try:
+                    ga._lib.check(L.gaast_hip_comm_unique_id(idbuf))
+                except ga.GaastError as e:
+                    ok, lib_comm_error = 0, str(e)
+            idt = torch.tensor(list(bytes(idbuf)) + [ok], dtype=torch.uint8, device=dev)
             dist.broadcast(idt, src=0)
-            idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)(*idt.cpu().tolist())
-            ga._lib.check(L.gaast_hip_comm_init(idbuf, rank, world))
-            nr = C.c_int()
-            ga._lib.check(L.gaast_hip_comm_count_ranks(C.byref(nr)))
-            lib_comm = nr.value == world
-            rccl_ranks = min(rccl_ranks, nr.value)
+            vals = idt.cpu().tolist()
+            if vals[-1]:
+                idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)(*vals[:-1])
+                try:
+                    ga._lib.check(L.gaast_hip_comm_init(idbuf, rank, world))
+                    nr = C.c_int()
+                    ga._lib.check(L.gaast_hip_comm_count_ranks(C.byref(nr)))
+                    joined = int(nr.value == world)
+                except ga.GaastError as e:
+                    joined, lib_comm_error = 0, str(e)
+            else:
+                joined = 0
+            # every rank must agree on which path the gather takes
+            agree = torch.tensor([joined], dtype=torch.int64, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            lib_comm = bool(agree.item())
+            if not lib_comm and lib_comm_error is None:
+                lib_comm_error = "a rank could not join the library communicator"
 
     wl = workload_spec(args.workload)
     n, dtype = wl["n"], wl["dtype"]
@@ -363,7 +383,7 @@ def main():
     # the root's result rows live inside the gathered buffer (no local copy at gather time)
     gathered_t = gathered = None
     want_gather = world > 1 and not args.no_gather
-    if want_gather and rank == 0 and not rehearsal:
+    if want_gather and rank == 0 and lib_comm:
         gathered_t = torch.empty((global_batch, out_len), device=dev, dtype=tdt)
         gathered = ga.DeviceMV.wrap_tensor(gathered_t, n, ga.GradeSet(out_mask))
         out_t = gathered_t[:batch]
@@ -459,69 +479,8 @@ def main():
                    "note": "one gaast_hip_eval of one input set + synchronize (the reference evaluates one input set per "
                            "eval()); the program is built once per SpecializedAst"}
 
-    # the one exchange of the path: result rows to rank 0.  Measured twice over the same K steps:
-    #   blocking   eval, then gaast_hip_gather_rows (one transfer per peer, all links at once)
-    #   overlapped gaast_hip_eval_gather: the shard in `chunks` chunks, chunk k travels while chunk k + 1 computes
-    gather = None
-    if want_gather:
-        sz = 4 if dtype == ga.F32 else 8
-        chunks = max(1, args.gather_chunks)
-        cnt = (C.c_int64 * world)(*counts)
-        if lib_comm:
-            def blocking():
-                spec.eval_batch(ins, batch, out=out)
-                ga._lib.check(L.gaast_hip_gather_rows(out._h, gathered._h if gathered is not None else None, cnt, 0))
-
-            def overlapped():
-                spec.eval_gather(ins, out, gathered, counts, root=0, n_chunks=chunks)
-            path = "gaast_hip_eval_gather / gaast_hip_gather_rows: RCCL send/recv, one direct transfer per peer"
-        else:
-            # rehearsal (ranks share a GPU, RCCL refuses that) or no library communicator: the same chunk schedule with
-            # torch.distributed collectives on host copies
-            from gaast_amd.sharding import chunk_span
-            per = max(counts)
-            def _gather_span(lo, hi, async_op):
-                send = torch.zeros((-(-per // chunks) if async_op else per, out_len), dtype=tdt)
-                send[:hi - lo] = out_t[lo:hi].cpu()
-                bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-                return dist.gather(send, bufs, dst=0, async_op=async_op), bufs
-
-            def blocking():
-                spec.eval_batch(ins, batch, out=out)
-                torch.cuda.synchronize()
-                _gather_span(0, batch, False)
-
-            def overlapped():
-                pend = []
-                for c in range(chunks):
-                    lo, hi = chunk_span(batch, chunks, c)
-                    sub_in = [ga.DeviceMV.wrap_tensor(t[lo:hi] if t.shape[0] == batch else t, n, g) for t, g in zip(in_t, wl["inputs"])]
-                    sub_out = ga.DeviceMV.wrap_tensor(out_t[lo:hi], n, ga.GradeSet(out_mask))
-                    if hi > lo:
-                        spec.eval_batch(sub_in, hi - lo, out=sub_out)
-                    torch.cuda.synchronize()
-                    pend.append(_gather_span(lo, hi, True))
-                for h, _ in pend:
-                    h.wait()
-            path = "torch.distributed gather of host copies (rehearsal: ranks share a GPU)" if rehearsal else "torch.distributed gather (library communicator unavailable)"
-        blocking()
-        overlapped()
-        w_block = timed(blocking, args.steps)
-        w_over = timed(overlapped, args.steps)
-        items_total = global_batch * args.steps
-        gather = {"path": path, "chunks": chunks, "bytes_per_rank": out_len * sz * batch, "bytes_total": out_len * sz * global_batch,
-                  "ms_per_step_eval_only": wall / args.steps * 1e3,
-                  "ms_per_step_blocking_gather": w_block / args.steps * 1e3,
-                  "ms_per_step_overlapped_gather": w_over / args.steps * 1e3,
-                  "value_without_gather": items_total / wall,
-                  "value_with_blocking_gather": items_total / w_block,
-                  "value_with_gather": items_total / w_over,
-                  "ms": max(0.0, (w_block - wall) / args.steps * 1e3)}
-        if rank == 0 and gathered_t is not None:
-            # the gathered rows of the LAST rank equal what that rank computed (spot check through a second gather)
-            gather["gathered_rows"] = int(gathered_t.shape[0])
-
-    if rank == 0:
+    def emit(gather):
+        """rank 0: the ONE JSON line"""
         items_total = global_batch * args.steps
         value = items_total / wall
         sz = 4 if dtype == ga.F32 else 8
@@ -574,6 +533,96 @@ def main():
             res["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
+    # the one exchange of the path: result rows to rank 0.  Measured twice over the same K steps:
+    #   blocking   eval, then gaast_hip_gather_rows (one transfer per peer, all links at once)
+    #   overlapped gaast_hip_eval_gather: the shard in `chunks` chunks, chunk k travels while chunk k + 1 computes
+    gather = None
+    if want_gather:
+        sz = 4 if dtype == ga.F32 else 8
+        chunks = max(1, args.gather_chunks)
+        cnt = (C.c_int64 * world)(*counts)
+        if lib_comm:
+            def blocking():
+                spec.eval_batch(ins, batch, out=out)
+                ga._lib.check(L.gaast_hip_gather_rows(out._h, gathered._h if gathered is not None else None, cnt, 0))
+
+            def overlapped():
+                spec.eval_gather(ins, out, gathered, counts, root=0, n_chunks=chunks)
+            path = "gaast_hip_eval_gather / gaast_hip_gather_rows: RCCL send/recv, one direct transfer per peer"
+        else:
+            # rehearsal (ranks share a GPU, RCCL refuses that: gloo on host copies) or no library communicator
+            # (torch.distributed's own RCCL on device tensors): the same chunk schedule with torch collectives
+            from gaast_amd.sharding import chunk_span
+            per = max(counts)
+            host = rehearsal
+            def _gather_span(lo, hi, rows, async_op):
+                send = torch.zeros((rows, out_len), dtype=tdt, device="cpu" if host else dev)
+                send[:hi - lo] = out_t[lo:hi].cpu() if host else out_t[lo:hi]
+                bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+                return dist.gather(send, bufs, dst=0, async_op=async_op), bufs
+
+            def blocking():
+                spec.eval_batch(ins, batch, out=out)
+                torch.cuda.synchronize()
+                _gather_span(0, batch, per, False)
+
+            def overlapped():
+                pend = []
+                for c in range(chunks):
+                    lo, hi = chunk_span(batch, chunks, c)
+                    sub_in = [ga.DeviceMV.wrap_tensor(t[lo:hi] if t.shape[0] == batch else t, n, g) for t, g in zip(in_t, wl["inputs"])]
+                    sub_out = ga.DeviceMV.wrap_tensor(out_t[lo:hi], n, ga.GradeSet(out_mask))
+                    if hi > lo:
+                        spec.eval_batch(sub_in, hi - lo, out=sub_out)
+                    torch.cuda.synchronize()
+                    pend.append(_gather_span(lo, hi, -(-per // chunks), True))
+                for h, _ in pend:
+                    h.wait()
+            path = ("torch.distributed gather of host copies (rehearsal: ranks share a GPU)" if rehearsal else
+                    "torch.distributed gather on device tensors (library communicator unavailable: " + str(lib_comm_error) + ")")
+        # The gather legs run over a communicator that cannot be rehearsed on a one-GPU box: if they hang or fail, the
+        # throughput line measured above is still printed (gather.error says what happened) and the job ends cleanly.
+        import threading
+        state = {"done": False}
+
+        def give_up():
+            if state["done"]:
+                return
+            if rank == 0:
+                emit({"path": path, "library_communicator": lib_comm, "chunks": chunks,
+                      "error": f"gather legs did not finish within {GATHER_WATCHDOG_S} s; throughput above is unaffected"})
+            os._exit(0)
+        watchdog = threading.Timer(GATHER_WATCHDOG_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            blocking()
+            overlapped()
+            w_block = timed(blocking, args.steps)
+            w_over = timed(overlapped, args.steps)
+            items_total = global_batch * args.steps
+            gather = {"path": path, "library_communicator": lib_comm, "chunks": chunks, "bytes_per_rank": out_len * sz * batch,
+                      "bytes_total": out_len * sz * global_batch,
+                      "ms_per_step_eval_only": wall / args.steps * 1e3,
+                      "ms_per_step_blocking_gather": w_block / args.steps * 1e3,
+                      "ms_per_step_overlapped_gather": w_over / args.steps * 1e3,
+                      "value_without_gather": items_total / wall,
+                      "value_with_blocking_gather": items_total / w_block,
+                      "value_with_gather": items_total / w_over,
+                      "ms": max(0.0, (w_block - wall) / args.steps * 1e3)}
+            if rank == 0 and gathered_t is not None:
+                gather["gathered_rows"] = int(gathered_t.shape[0])
+                # rows of the last shard, as the root received them, against what a second, blocking gather delivers
+                gather["last_shard_checksum"] = float(gathered_t[-counts[-1]:].double().sum().item())
+        except Exception as e:      # a failed collective on this rank: say so, keep the throughput line
+            gather = {"path": path, "library_communicator": lib_comm, "chunks": chunks, "error": f"{type(e).__name__}: {e}"}
+        state["done"] = True
+        watchdog.cancel()
+
+    if rank == 0:
+        emit(gather)
+    if gather is not None and "error" in gather:
+        os._exit(0)          # some rank may be stuck in a collective: no further rendezvous
     if world > 1:
         dist.barrier()
         if lib_comm:

@@ -8,11 +8,19 @@
 #define GAAST_MFMA32_DPP 0
 #endif
 #ifndef GAAST_MFMA16_BSIGN_MUL
-#define GAAST_MFMA16_BSIGN_MUL 1
+#define GAAST_MFMA16_BSIGN_MUL 0
 #endif
 #ifndef GAAST_DENSE_NO_CANON
 #define GAAST_DENSE_NO_CANON 0
 #endif
+#ifndef GAAST_MFMA16_SETPRIO
+#define GAAST_MFMA16_SETPRIO 1
+#endif
+#ifndef GAAST_MFMA16_UNROLL
+#define GAAST_MFMA16_UNROLL 1
+#endif
+#define GAAST_STR2(x) #x
+#define GAAST_STR(x) GAAST_STR2(x)
 
 namespace gaast {
 
@@ -613,54 +621,49 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // Operand images: A in plain blade order, B in the vector kernel's quad-rotated order; items are 2^(n+1) + 16
 // words apart so that the four items of a wave sit on different banks.
 // ------------------------------------------------------------------------------------------
-// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): register prefetch of
-// the next group's rows.  Otherwise: the general staging of stage_operands (partial grade sets, strided / unaligned rows).
+// One workgroup = ONE group of four items (n = 8: a single wave, n = 9: two waves), persistent: no synchronisation
+// between the groups a CU works on, their staging / product / store phases drift apart and fill each other's stalls.
+// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): the rows of the next group
+// are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging of
+// stage_operands (partial grade sets, strided / unaligned rows).
 template <bool DEGENERATE, int NDIM, bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gp_mfma16(DenseArgs<float> p) {
+__global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gp_mfma16(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     constexpr int n = NDIM;                       // 8 or 9
     constexpr int N = 1 << n;
     constexpr int H = 1 << (n - 4);               // number of 16-blocks
-    constexpr int WPG = H >> 4;                       // waves per group of four items (16 result columns each)
-    constexpr int GPB = 4 / WPG;                  // groups per workgroup
-    constexpr int IPB = 4 * GPB;                  // items per workgroup
+    constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
+    constexpr int IPB = 4;                        // items per workgroup pass: the four blocks of the instruction
     constexpr int item_stride = 2 * N + 16;
-    constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row
-    constexpr int PF = IPB * COUNT4 / 256;        // pieces per thread and operand (4)
-    constexpr int IT_STEP = 256 / COUNT4;         // item distance between a thread's pieces
+    constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row == THREADS: thread t moves piece t of every row
+    static_assert(COUNT4 == THREADS, "one 16-byte piece of each row per thread");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
-    // Persistent workgroups.  Fast path (both operands hold every blade in consecutive, 16-byte aligned rows): the
-    // rows of the NEXT group of items are fetched into registers while the matrix cores work on the current one, so
-    // that the HBM latency of a group hides under the previous group's products.  A thread's pieces sit at the same
-    // place of every row it touches (256 is a multiple of COUNT4): its index-map words are loaded once.
-    constexpr bool fast = FAST;
-    const int my_j4 = tid % COUNT4, my_it = tid / COUNT4;
-    // byte address of each of the thread's 4 + 4 components inside the first item's images it touches (further items
-    // are a compile-time distance away), and their negate bits
+
+    // byte address of each of the thread's 4 + 4 components inside item 0's images (item k is a compile-time distance
+    // away), and their negate bits
     uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    if (fast) {
-        const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[my_j4], mr = reinterpret_cast<const uint4*>(p.right_map)[my_j4];
+    if (FAST) {
+        const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[tid], mr = reinterpret_cast<const uint4*>(p.right_map)[tid];
         const uint32_t mls[4] = {ml.x, ml.y, ml.z, ml.w}, mrs[4] = {mr.x, mr.y, mr.z, mr.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            wa[c] = (((mls[c] >> 16) & 0x7fffu) + uint32_t(my_it * item_stride)) << 2;
-            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(my_it * item_stride + N)) << 2;
+            wa[c] = ((mls[c] >> 16) & 0x7fffu) << 2;
+            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(N)) << 2;
             sa[c] = mls[c] & 0x80000000u;     // a folded Negation / Reverse / GradeInvolution, or the basis permutation's sign
             sb[c] = mrs[c] & 0x80000000u;
         }
     }
-    float4 pf_l[PF], pf_r[PF];
+    float4 pf_l[IPB], pf_r[IPB];
     auto fetch = [&](int64_t g) {
         const int64_t it0 = g * IPB;
         const int cnt = int(p.batch - it0 < IPB ? p.batch - it0 : IPB);
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int it = my_it + k * IT_STEP;
-            if (it < cnt) {
-                pf_l[k] = *reinterpret_cast<const float4*>(p.left + (it0 + it) * p.left_stride + (my_j4 << 2));
-                pf_r[k] = *reinterpret_cast<const float4*>(p.right + (it0 + it) * p.right_stride + (my_j4 << 2));
+        for (int k = 0; k < IPB; ++k) {
+            if (k < cnt) {   // (uniform) row base + the thread's piece
+                pf_l[k] = reinterpret_cast<const float4*>(p.left + (it0 + k) * p.left_stride)[tid];
+                pf_r[k] = reinterpret_cast<const float4*>(p.right + (it0 + k) * p.right_stride)[tid];
             }
         }
     };
@@ -673,16 +676,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (canon) y = 0.f + y;           // the reference's zero-init + add_grades_from copy: 0.0 + x
 #endif
             y = __uint_as_float(__float_as_uint(y) ^ sg[c]);
-            *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * IT_STEP * item_stride * 4)) = y;
+            *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * item_stride * 4)) = y;
         }
     };
-    if (fast && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
+    if (FAST && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int grp = wave / WPG, tile = wave - grp * WPG;
-    const int blk = lane >> 4, i = lane & 15;
-    const int it = grp * 4 + blk;                 // this lane's item (operand side); may be beyond nitems: not stored
-    const float* As = smem + it * item_stride;
+    const int tile = tid >> 6, lane = tid & 63;   // wave <-> 16 result columns
+    const int blk = lane >> 4, i = lane & 15;     // lane's item of the group (operand side), row / column inside the tile
+    const float* As = smem + blk * item_stride;
     const float* Bs = As + N;
     const int c_hi = (tile << 4) | i;
 
@@ -719,45 +720,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t bq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[q] = (uint32_t(c_hi) << 6) | (uint32_t((q ^ (c_hi >> 2)) & 3) << 4);
-    // where this lane's results go: register 4 b + r = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + (lane & 15)
+    // where this lane's results go: register 4 b + r = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + (lane & 15):
+    // byte offset in the result row, sign of the basis permutation, "not produced"
     const int rg = lane >> 4;
-    int32_t om[4];
+    uint32_t ooff[4], osg[4];
+    bool ook[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) om[r] = p.out_map[(c_hi << 4) + 4 * rg + r];
+    for (int r = 0; r < 4; ++r) {
+        const int32_t w = p.out_map[(c_hi << 4) + 4 * rg + r];
+        ook[r] = w >= 0;
+        ooff[r] = uint32_t(w & 0x3fffffff) << 2;
+        osg[r] = (uint32_t(w) & 0x40000000u) << 1;
+    }
 
     for (int64_t g = blockIdx.x; g < num_groups; g += gridDim.x) {
         const int64_t item0 = g * IPB;
         const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
         // ---- both operands of the group's items into their LDS images ----
-        if (fast) {
+        if (FAST) {
 #pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int sit = my_it + k * IT_STEP;
-                if (sit < nitems) {
+            for (int k = 0; k < IPB; ++k) {
+                if (k < nitems) {
                     scatter4(k, pf_l[k], wa, sa, p.canon_left);
                     scatter4(k, pf_r[k], wb, sb, p.canon_right);
                 }
             }
         } else {
             if (!p.left_full || !p.right_full) {
-                for (int e = tid; e < nitems * item_stride; e += 256) smem[e] = 0.f;
+                for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
                 __syncthreads();
             }
-            stage_operands<float, 256>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid);
-            stage_operands<float, 256>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+            stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                           p.canon_left, smem, item_stride, nitems, tid);
+            stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                           p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
         }
-        __syncthreads();
-        if (fast && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
+        __syncthreads();   // one wave at n = 8: no wait
+        if (FAST && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
 
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
         auto one_step = [&](int a_hi) {
-            // block sign and (DEGENERATE) block mask of this lane's B block: integer operations only -- bitwise vector
-            // instructions issue beside the matrix-core chain, floating-point ones (a multiply by +-1) do not
-            // (tools/microbench/mfma16_loop.hip)
+            // block sign and (DEGENERATE) block mask of this lane's B block
             const uint32_t sbit = ((sign_bits >> a_hi) & 1u) << 31;
             uint32_t keep = 0xffffffffu;
             if (DEGENERATE) keep = ((zero_bits >> a_hi) & 1u) ? 0u : 0xffffffffu;
@@ -800,25 +806,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         // (unrolling these loops makes the block index a constant but costs all the registers)
         constexpr int half = H >> 1;
-#pragma unroll 1
+#if GAAST_MFMA16_SETPRIO
+        __builtin_amdgcn_s_setprio(2);   // waves in their product phase go first
+#endif
+_Pragma(GAAST_STR(unroll GAAST_MFMA16_UNROLL))
         for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
 #pragma unroll
         for (int k = 0; k < 16; ++k)  // (-1)^(|a_hi| |k|) for odd |a_hi|
             amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
-#pragma unroll 1
+_Pragma(GAAST_STR(unroll GAAST_MFMA16_UNROLL))
         for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
 #pragma unroll
         for (int k = 0; k < 16; ++k)  // back to the even-|a_hi| pattern for the next group
             amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
+#if GAAST_MFMA16_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
-        // ---- results -> graded rows ----
+        // ---- results -> graded rows: (uniform) row base + the lane's byte offsets ----
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int item = grp * 4 + b;
-            if (item < nitems) {
-                float* orow = p.out + (item0 + item) * p.out_stride;
+            if (b < nitems) {
+                unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + (item0 + b) * p.out_stride);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store_result<float>(orow, om[r], acc[4 * b + r], p.beta);
+                for (int r = 0; r < 4; ++r) {
+                    if (ook[r]) {
+                        float* q = reinterpret_cast<float*>(orow + ooff[r]);
+                        const float v = __uint_as_float(__float_as_uint(acc[4 * b + r]) ^ osg[r]);
+                        *q = p.beta ? *q + v : v;
+                    }
+                }
             }
         }
         __syncthreads();   // the LDS images are rewritten by the next group

@@ -245,10 +245,9 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         }
         if (s.use_mfma16) {
             if constexpr (!is_f64) {
-                const int wpg = 1 << (n - 8);                  // waves per group of four items
-                s.threads = 256;
-                s.items_per_block = 4 * (4 / wpg);
-                s.lds = size_t(s.items_per_block) * size_t((2 << n) + 16) * sizeof(float);
+                s.threads = 64 << (n - 8);                     // one wave per 16 result columns of a group of four items
+                s.items_per_block = 4;
+                s.lds = size_t(4) * size_t((2 << n) + 16) * sizeof(float);
                 // [0]: general staging; [1]: register prefetch, when both operands are full rows that turn out
                 // contiguous and 16-byte aligned at launch
                 using KernD = void (*)(DenseArgs<float>);
