@@ -431,7 +431,7 @@ def main():
     # the same products through the opt-in matrix-representation kernel (not the reference's summation
     # order, so never `value`): reported beside the headline, with its distance from the default path
     alt = None
-    if args.workload in ("r12", "r12d", "r8") and rank == 0 and world == 1 and not args.no_alt:
+    if args.workload in ("r12", "r12d", "r8", "r8d") and rank == 0 and world == 1 and not args.no_alt:
         spec_alt = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
         out_alt_t = torch.empty_like(out_t)
         out_alt = ga.DeviceMV.wrap_tensor(out_alt_t, n, ga.GradeSet(out_mask))

@@ -56,14 +56,14 @@ struct SpinorArgs {
     int64_t batch;
 };
 
-template <int N>
-__device__ __forceinline__ void wht(float (&v)[N]) {
+template <int N, typename T = float>
+__device__ __forceinline__ void wht(T (&v)[N]) {
 #pragma unroll
     for (int hlf = 1; hlf < N; hlf <<= 1) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if ((i & hlf) == 0) {
-                const float a = v[i], b = v[i | hlf];
+                const T a = v[i], b = v[i | hlf];
                 v[i] = a + b;
                 v[i | hlf] = a - b;
             }
@@ -651,6 +651,199 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 const uint32_t eo = entry(om, u);
                 float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
                 val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
+                if (p.out_full && !p.beta) {
+                    orow[64 * u] = val;
+                } else if (!(eo & 2u)) {
+                    orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The wave-per-item kernel in f64 (the reference's value type) for n = 7..10: the same one-plane algorithm on
+// v_mfma_f64_16x16x4_f64.  The D x D result (D = 16 at n <= 8, 32 at n = 9, 10) is TB x TB tiles of 16 x 16
+// (TB = D / 16); lane (kq, i16) feeds row / column 16 b + i16 of tile row / column b with the k = 4 s + kq slice.
+// Planes of doubles: 4.3 KB / 16.9 KB of LDS per item.  Error bound 64 * 2^-52 |A|_2 |B|_2, like the n = 11, 12 kernel.
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int M, int LAMBIT>
+__global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    constexpr int D = 1 << M, LD = D + 1, P = D * LD;
+    constexpr int NE = D * D, EPL = NE / 64;
+    constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
+    constexpr int FWD_PASSES = 4 * D / 64, INV_PASSES = 4 * D / 64;
+    constexpr int TB = D / 16;                    // tiles per side
+    constexpr int NSTEPS = D / 4;                 // k = 4 s + kq
+    const int lane = threadIdx.x;
+    const double* left = static_cast<const double*>(p.left);
+    const double* right = static_cast<const double*>(p.right);
+    double* outp = static_cast<double*>(p.out);
+
+    uint32_t lm[EPL / 2], rm[EPL / 2], om[EPL / 2];
+#pragma unroll
+    for (int w = 0; w < EPL / 2; ++w) {
+        lm[w] = uint32_t(p.left_map[lane + 128 * w]) | (uint32_t(p.left_map[lane + 128 * w + 64]) << 16);
+        rm[w] = uint32_t(p.right_map[lane + 128 * w]) | (uint32_t(p.right_map[lane + 128 * w + 64]) << 16);
+        om[w] = uint32_t(p.out_map[lane + 128 * w]) | (uint32_t(p.out_map[lane + 128 * w + 64]) << 16);
+    }
+    auto entry = [](const uint32_t (&m)[EPL / 2], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
+    double va[EPL], vb[EPL];
+    const bool rows_full = p.left_len == NE && p.right_len == NE;
+    auto fetch = [&](int64_t item) {
+        const double* lrow = left + item * p.left_stride + lane;
+        const double* rrow = right + item * p.right_stride + lane;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = lane + 64 * u;
+            va[u] = (rows_full || e < p.left_len) ? lrow[64 * u] : 0.0;
+            vb[u] = (rows_full || e < p.right_len) ? rrow[64 * u] : 0.0;
+        }
+    };
+    int64_t item = blockIdx.x;
+    if (item < p.batch) fetch(item);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    for (; item < p.batch; item += gridDim.x) {
+#pragma unroll
+        for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        if (!p.left_full || !p.right_full) {
+            for (int j = lane; j < 2 * P; j += 64) smem[j] = 0.0;
+            __syncthreads();
+        }
+        {
+            auto put = [&](double* plane, uint32_t e, double a, int canon) {
+                if (canon) a = 0.0 + a;
+                if (e & 1u) a = -a;
+                *reinterpret_cast<double*>(reinterpret_cast<char*>(plane) + ((e & 0x7ffcu) << 1)) = a;
+            };
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                put(smem, entry(lm, u), va[u], p.canon_left);
+                put(smem + P, entry(rm, u), vb[u], p.canon_right);
+            }
+        }
+        __syncthreads();
+        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+
+        // one transform per row, two threads per row: (operand, x, half) = 4 D half-rows over 64 lanes
+#pragma unroll
+        for (int j = 0; j < FWD_PASSES; ++j) {
+            const int hidx = lane + 64 * j;
+            const int hb = hidx & 1;
+            double* row = smem + (hidx >> (M + 1)) * P + ((hidx >> 1) & (D - 1)) * LD;
+            const double sg = hb ? -1.0 : 1.0;
+            double v[D / 2];
+#pragma unroll
+            for (int c = 0; c < D / 2; ++c) v[c] = row[c] + row[c + D / 2] * sg;
+            wht<D / 2, double>(v);
+#pragma unroll
+            for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
+        }
+        __syncthreads();
+
+        double4v gx[TB * TB], gy[TB * TB], gz[TB * TB], bank_re[TB * TB];
+#pragma unroll
+        for (int t = 0; t < TB * TB; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gx[t][r] = 0.0;
+                gy[t][r] = 0.0;
+                gz[t][r] = 0.0;
+                bank_re[t][r] = 0.0;
+            }
+#pragma unroll
+        for (int s2 = 0; s2 < NSTEPS; ++s2) {
+            const int k = 4 * s2 + kq;
+            const bool hi = LAMBIT >= 0 && ((4 * s2) & LAM);
+            double pa[TB], qa[TB], pb[TB], qb[TB];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int rc = 16 * b + i16;                       // row of A / column of B this lane feeds
+                const int idx = (rc ^ k) * LD + k;
+                pa[b] = smem[idx];
+                pb[b] = smem[P + idx];
+                qa[b] = LAMBIT < 0 ? pa[b] : (hi ? smem[idx - LAM] : smem[idx + LAM]);
+                qb[b] = LAMBIT < 0 ? pb[b] : (hi ? smem[P + idx - LAM] : smem[P + idx + LAM]);
+                if (p.has_alpha && (rc >> (M - 1))) {              // sigma of row / column rc
+                    qa[b] = -qa[b];
+                    qb[b] = -qb[b];
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < TB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < TB; ++cb) {
+                    const int t = rb * TB + cb;
+                    gx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb], pb[cb], gx[t], 0, 0, 0);
+                    gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cb], gy[t], 0, 0, 0);
+                    gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cb] + qb[cb], gz[t], 0, 0, 0);
+                }
+            if (s2 == NSTEPS / 2 - 1) {   // k_top = 0 half done
+#pragma unroll
+                for (int t = 0; t < TB * TB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < TB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < TB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = rb * TB + cb;
+                    // accumulator layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 r
+                    const int rr = 16 * rb + kq + 4 * r, cc = 16 * cb + i16;     // element (row rr, column cc) of the product
+                    const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                    smem[(rr ^ cc) * LD + rr] = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                    smem[P + (rr ^ cc) * LD + rr] = gx[t][r] - gy[t][r];
+                }
+        __syncthreads();
+        // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
+        {
+            constexpr int B1 = LAMBIT == M - 2 ? M - 2 : M - 1, B2 = LAMBIT == M - 2 ? M - 1 : M - 2;
+            constexpr int Q = D / 4;
+            double v[INV_PASSES][Q];
+#pragma unroll
+            for (int j = 0; j < INV_PASSES; ++j) {
+                const int tix = lane + 64 * j;
+                const int x = tix >> 2, h1 = (tix >> 1) & 1, h2 = tix & 1;
+                const int xi = p.has_alpha ? (x >> (M - 1)) & 1 : 0;
+                const int f = LAMBIT >= 0 ? (xi ^ h1) : xi;
+                const double* q = smem + f * P + x * LD;
+                const double sc = 0.5 / double(D);
+                const double s1 = h1 ? -sc : sc, s2f = h2 ? -1.0 : 1.0;
+#pragma unroll
+                for (int c = 0; c < Q; ++c) {
+                    const double lo = q[c] * sc + q[c | (1 << B1)] * s1;
+                    const double up = q[c | (1 << B2)] * sc + q[c | (1 << B1) | (1 << B2)] * s1;
+                    v[j][c] = lo + up * s2f;
+                }
+                wht<Q, double>(v[j]);
+            }
+            __syncthreads();   // every pass has read its planes before any result lands in plane 0
+#pragma unroll
+            for (int j = 0; j < INV_PASSES; ++j) {
+                const int tix = lane + 64 * j;
+                const int x = tix >> 2, h1 = (tix >> 1) & 1, h2 = tix & 1;
+                double* o = smem + x * LD + (h1 << B1) + (h2 << B2);
+#pragma unroll
+                for (int c = 0; c < Q; ++c) o[c] = v[j][c];
+            }
+        }
+        __syncthreads();
+        {
+            double* orow = outp + item * p.out_stride + lane;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const uint32_t eo = entry(om, u);
+                double val = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(smem) + ((eo & 0xfffcu) << 1));
+                if (eo & 1u) val = -val;
                 if (p.out_full && !p.beta) {
                     orow[64 * u] = val;
                 } else if (!(eo & 2u)) {

@@ -428,7 +428,6 @@ struct Lowering {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return false;
         const int n = d.vec_space_dim;
         if (n < 7 || n > 12) return false;
-        if (plan.dtype != GAAST_F32 && n < 11) return false;   // f64: the 64 x 64 kernel only
         if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return false;
         for (int i = 0; i < n; ++i)
             if (d.metric_diag[i] != 1.0 && d.metric_diag[i] != -1.0) return false;

@@ -215,13 +215,13 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         if (s.use_spinor) {
             using KernS = void (*)(SpinorArgs);
             const int m = s.use_spinor;
-            if (is_f64 && m != 6)
-                return set_err(GAAST_ERR_UNIMPLEMENTED, "f64 matrix-representation product exists for n = 11, 12 only");
             const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
             s.lds = (m == 6 ? 2 * plane : 2 * D * (D + 1)) * sizeof(T);
             const int lb5 = s.spinor_lam_bit;
             KernS kern = nullptr;
-            if (is_f64) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
+            if (is_f64 && m == 6) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
+            else if (is_f64 && m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1d<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1d<5, 3> : &k_gp_spinor_wave1d<5, -1>;
+            else if (is_f64) kern = lb5 == 3 ? &k_gp_spinor_wave1d<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1d<4, 2> : &k_gp_spinor_wave1d<4, -1>;
             else if (m == 6) kern = lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>;
             else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
             else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;

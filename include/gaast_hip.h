@@ -130,7 +130,7 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_NO_MFMA 0x8u        /* dense products stay on the vector-FMA kernel (A/B testing) */
 #define GAAST_FLAG_NO_JIT 0x10u        /* small programs run on the LDS interpreter kernel, not on hiprtc-specialised code */
 /* OPT-IN, not the reference's algorithm: dense geometric products of a non-degenerate algebra (f32:
- * dimension 7..12; f64: 11, 12) go through the 2^m x 2^m complex matrix representation (at n = 12: 21x fewer
+ * dimension 7..12, f32 and f64) go through the 2^m x 2^m complex matrix representation (at n = 12: 21x fewer
  * multiply-adds, all on the matrix cores).  Equal to eval.rs:61-86 in exact arithmetic; the error is bounded norm-wise,
  * |err_S| <= 64 eps(dtype) |A|_2 |B|_2, not per component.  Never selected without this flag. */
 #define GAAST_FLAG_SPINOR_GEMM 0x20u

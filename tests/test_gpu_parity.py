@@ -361,35 +361,42 @@ def test_spinor_gemm_basis_blades_exact(metric):
     (8, (2, 3, 6, 7), "lam=3"), (8, (2, 3, 4), "lam=2"), (8, (0, 1, 2, 3, 4, 6), "lam=3"), (8, (0, 3, 4, 7), "lam=-1"), (8, (1, 3, 5, 7), "lam=-1"),
     (10, (2, 3, 6, 7, 8, 9), "lam=4"), (10, (0, 1, 3, 4, 8), "lam=3"), (10, (1, 2, 5, 7, 9), "lam=-1"), (10, (2, 4, 5, 8, 9), "lam=4"),
     (10, (1, 3, 5, 7, 9), "lam=-1")])
-def test_spinor_gemm_smaller_dimensions(n, neg, variant):
-    """n = 8 and 10 on the wave-per-item kernels, odd n as the subalgebra of n + 1."""
+@pytest.mark.parametrize("dtype", [ga.F32, ga.F64])
+def test_spinor_gemm_smaller_dimensions(n, neg, variant, dtype):
+    """n = 8 and 10 on the wave-per-item kernels (f32: k_gp_spinor_wave1, f64: k_gp_spinor_wave1d), odd n as the
+    subalgebra of n + 1."""
+    if dtype == ga.F64 and n == 11:
+        pytest.skip("n = 11 in f64 runs on k_gp_spinor12d: test_spinor_gemm_f64")
     metric = [-1.0 if i in neg else 1.0 for i in range(n)]
     batch = 67
     rng = np.random.default_rng(30 + n)
-    rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
-    got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    npdt, eps = (np.float32, 2.0 ** -23) if dtype == ga.F32 else (np.float64, 2.0 ** -52)
+    rows = {0: rows_of(n, full_grades(n), batch, rng, npdt), 1: rows_of(n, full_grades(n), batch, rng, npdt)}
+    got, mask, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
     assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
     if variant:
         assert any(variant in l for l in spec.launches()), spec.launches()
     for i in range(0, batch, 11):
         A, Bb = row_to_bits(n, full_grades(n), rows[0][i]), row_to_bits(n, full_grades(n), rows[1][i])
         want = bits_to_row(n, full_grades(n), gp_bits(n, metric, A, Bb))
-        bound = 64 * 2.0 ** -23 * np.linalg.norm(rows[0][i].astype(np.float64)) * np.linalg.norm(rows[1][i].astype(np.float64))
+        bound = 64 * eps * np.linalg.norm(rows[0][i].astype(np.float64)) * np.linalg.norm(rows[1][i].astype(np.float64))
         err = np.abs(got[i].astype(np.float64) - want).max()
         assert err <= bound, (i, err, bound)
 
 
+@pytest.mark.parametrize("dtype", [ga.F32, ga.F64])
 @pytest.mark.parametrize("n", [8, 9, 10])
-def test_spinor_gemm_smaller_dimensions_basis_blades_exact(n):
+def test_spinor_gemm_smaller_dimensions_basis_blades_exact(n, dtype):
     metric = [-1.0 if i % 3 == 1 else 1.0 for i in range(n)]
     N = 1 << n
     rng = np.random.default_rng(40 + n)
     batch = 300
     a_idx, b_idx = rng.integers(0, N, batch), rng.integers(0, N, batch)
-    ra, rb = np.zeros((batch, N), np.float32), np.zeros((batch, N), np.float32)
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    ra, rb = np.zeros((batch, N), npdt), np.zeros((batch, N), npdt)
     ra[np.arange(batch), a_idx] = 1.0
     rb[np.arange(batch), b_idx] = 1.0
-    got, _, spec = hip_eval_batch(_gp(n), metric, {0: ra, 1: rb}, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    got, _, spec = hip_eval_batch(_gp(n), metric, {0: ra, 1: rb}, batch, dtype=dtype, flags=ga.FLAG_SPINOR_GEMM)
     assert any("product_spinor_gemm" in l for l in spec.launches())
     from helpers import blades_in_row_order
     blades = blades_in_row_order(n, full_grades(n))
@@ -398,14 +405,16 @@ def test_spinor_gemm_smaller_dimensions_basis_blades_exact(n):
     alg = ga.MetricAlgebra(metric)
     for i in range(batch):
         res, coeff = alg.ortho_basis_blades_gp(int(blades[a_idx[i]]), int(blades[b_idx[i]]))
-        want = np.zeros(N, np.float32)
+        want = np.zeros(N, npdt)
         want[pos_of[res]] = coeff
         assert np.array_equal(got[i], want), (i,)
 
 
-@pytest.mark.parametrize("n,midx", [(12, 0), (12, 1), (12, 3), (12, 4), (12, 5), (12, 6), (11, 0)])
+@pytest.mark.parametrize("n,midx", [(12, 0), (12, 1), (12, 3), (12, 4), (12, 5), (12, 6), (11, 0),
+                                    (10, 0), (10, 1), (10, 3), (10, 4), (10, 5), (10, 6), (9, 1), (8, 0), (8, 1), (8, 3), (8, 4), (8, 5), (8, 6), (7, 0)])
 def test_spinor_gemm_f64(n, midx):
-    """the same path in f64 (the reference's value type): bound 64 * 2^-52 * |A| |B|, every index-basis case"""
+    """the same path in f64 (the reference's value type): bound 64 * 2^-52 * |A| |B|, every index-basis case; n = 11, 12
+    on k_gp_spinor12d, n = 7..10 on the wave-per-item k_gp_spinor_wave1d (16 x 16 f64 MFMA tiles)"""
     metric = SPINOR_METRICS[midx][:n]
     batch = 5
     rng = np.random.default_rng(50 + midx)
@@ -443,7 +452,8 @@ def test_spinor_gemm_f64_basis_blades_exact():
         assert np.array_equal(got[i], want), (i,)
 
 
-@pytest.mark.parametrize("n,dtype", [(12, ga.F32), (12, ga.F64), (11, ga.F64), (10, ga.F32), (8, ga.F32), (7, ga.F32)])
+@pytest.mark.parametrize("n,dtype", [(12, ga.F32), (12, ga.F64), (11, ga.F64), (10, ga.F32), (8, ga.F32), (7, ga.F32),
+                                     (10, ga.F64), (9, ga.F64), (8, ga.F64), (7, ga.F64)])
 def test_spinor_gemm_partial_grades_unary_folding_and_shared_operand(n, dtype):
     """rotor-like even operand (shared by all items), reversed on the fly, odd result only: partial tables,
     zero-filled planes, folded unary signs, a batch-1 operand -- on every kernel of the path."""
