@@ -1,6 +1,7 @@
 // C ABI of the host-side mirror (include/gaast_expr.h).
 #include <atomic>
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "../common/algebra.hpp"
@@ -132,9 +133,9 @@ gaast_expr_t gaast_expr_vinv(gaast_expr_t e) { return wrap(make_unary(ExprNode::
 gaast_spec_t gaast_expr_specialize(gaast_expr_t e, int n, const double* metric_diag,
                                    uint64_t materialize_limit) {
     try {
-        auto* s = new gaast_spec_s;
+        auto s = std::make_unique<gaast_spec_s>();   // released if specialize() reports a reference panic by throwing
         s->ast = specialize(e->node, n, metric_diag, materialize_limit);
-        return s;
+        return s.release();
     } catch (const SpecError& err) {
         g_err = err.msg;
         return nullptr;
