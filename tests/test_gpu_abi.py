@@ -258,3 +258,51 @@ def test_entry_points_make_the_library_device_current_on_any_thread():
     t.start()
     t.join()
     assert "err" not in box and np.array_equal(box["got"], want)
+
+
+def test_eval_gather_chunk_schedule_on_a_one_rank_communicator():
+    """gaast_hip_eval_gather == gaast_hip_eval + gaast_hip_gather_rows for every chunking (more chunks than items, one
+    chunk, ragged chunks), into a separate destination and into `out` itself; argument errors are statuses."""
+    L = _lib.lib()
+    ga.init_device()
+    rng = np.random.default_rng(77)
+    build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, [0, 2, 4], 5), B.input(1, [1], 5))
+    cga = [1.0, 1.0, 1.0, 1.0, -1.0]
+    spec = build(HipBackend()).specialize(cga)
+    # without a communicator: a status, not a crash
+    cnt1 = (C.c_int64 * 1)(5)
+    o5 = ga.DeviceMV.alloc(5, [1, 3, 5], 5)
+    assert L.gaast_hip_gather_rows(o5._h, o5._h, cnt1, 0) == 5          # GAAST_ERR_RCCL
+    idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+    _lib.check(L.gaast_hip_comm_unique_id(idbuf))
+    _lib.check(L.gaast_hip_comm_init(idbuf, 0, 1))
+    try:
+        assert L.gaast_hip_comm_init(idbuf, 0, 1) == 5                  # a second communicator is refused
+        n = C.c_int()
+        _lib.check(L.gaast_hip_comm_count_ranks(C.byref(n)))
+        assert n.value == 1
+        for batch, chunks in ((1, 4), (3, 7), (64, 1), (257, 4), (1000, 3)):
+            rows = {0: rows_of(5, [0, 2, 4], batch, rng), 1: rows_of(5, [1], batch, rng)}
+            want, _ = oracle_eval_batch(build, cga, rows, batch)
+            ins = [ga.DeviceMV.from_rows(5, [0, 2, 4], rows[0]), ga.DeviceMV.from_rows(5, [1], rows[1])]
+            out = ga.DeviceMV.alloc(5, [1, 3, 5], batch)
+            gathered = ga.DeviceMV.alloc(5, [1, 3, 5], batch)
+            spec.eval_gather(ins, out, gathered, [batch], root=0, n_chunks=chunks)
+            _lib.check(L.gaast_hip_synchronize())
+            assert np.array_equal(gathered.download_rows(), want) and np.array_equal(out.download_rows(), want)
+            out2 = ga.DeviceMV.alloc(5, [1, 3, 5], batch)               # `out` is the root's range of `gathered`
+            spec.eval_gather(ins, out2, out2, [batch], root=0, n_chunks=chunks)
+            _lib.check(L.gaast_hip_synchronize())
+            assert np.array_equal(out2.download_rows(), want)
+        # argument checks
+        bad = (C.c_int64 * 1)(2000)
+        handles = (C.c_void_p * 2)(ins[0]._h, ins[1]._h)
+        assert L.gaast_hip_eval_gather(spec.program(), handles, 2, out._h, gathered._h, bad, 0, 4) == 6       # counts[rank] > batch
+        ok = (C.c_int64 * 1)(1000)
+        assert L.gaast_hip_eval_gather(spec.program(), handles, 2, out._h, gathered._h, ok, 0, 0) == 6        # n_chunks < 1
+        assert L.gaast_hip_eval_gather(spec.program(), handles, 2, out._h, gathered._h, ok, 1, 4) == 6        # root out of range
+        assert L.gaast_hip_eval_gather(spec.program(), handles, 2, out._h, None, ok, 0, 4) == 6               # root without destination
+    finally:
+        _lib.check(L.gaast_hip_comm_destroy())
+    r, w = C.c_int(), C.c_int()
+    assert L.gaast_hip_comm_info(C.byref(r), C.byref(w)) == 5
