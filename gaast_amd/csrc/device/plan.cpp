@@ -971,7 +971,28 @@ bool try_fuse(Plan& plan) {
         const int out_len = int(plan.out_layout.row_len);
         const size_t lds_out_need = size_t(64) * size_t(padded_len(out_len)) * esz;
         const bool out_via_lds = lds_out_need <= lds_budget;
-        const size_t lds_total = std::max(lds_in, out_via_lds ? lds_out_need : size_t(0));
+        // Rows too long for the budget go through ONE shared 64 x 144-byte buffer, 128 bytes (a cache line) of every
+        // row at a time: 8 lanes move one row's line, a wave instruction 8 whole lines (so the rows need not even be
+        // contiguous, only 16-byte aligned with a 16-byte multiple stride).  Lines of a row are consumed one after the
+        // other: a few more barriers (single-wave workgroups: cheap), the same coalescing.
+        const int line_plen = int(144 / esz);   // padded line in elements: 9 x 16 bytes, odd -> conflict-free both ways
+        // (programs with big slabs are register-bound: the transposition's temporaries would spill -- measured on full R^6
+        // f32 products, 193 elements: 1.93 -> 1.30 TB/s -- so they keep the row-per-lane form)
+        auto line_ok = [&](int len) { return slab <= 128 && size_t(len) * esz >= 128 && (size_t(len) * esz) % 16 == 0; };
+        std::vector<char> by_line(f.fused_inputs.size(), 0);
+        bool any_line = false;
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i)
+            if (lds_off[i] < 0 && line_ok(int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len))) by_line[i] = 1, any_line = true;
+        const bool out_by_line = !out_via_lds && line_ok(out_len);
+        any_line = any_line || out_by_line;
+        const size_t line_bytes = any_line ? size_t(64) * 144 : 0;
+        if (any_line && lds_in + line_bytes > 12 * 1024 + 1024) {   // keep >= 12 waves per CU resident: drop the line path
+            std::fill(by_line.begin(), by_line.end(), 0);
+            any_line = false;
+        }
+        const size_t line_off = lds_in;                      // the shared line buffer sits after the span regions
+        const bool out_line = any_line && out_by_line;
+        const size_t lds_total = std::max(lds_in + (any_line ? line_bytes : 0), out_via_lds ? lds_out_need : size_t(0));
         const bool coalesce = !(plan.flags & GAAST_FLAG_NO_COALESCE) && lds_total > 0;
         const int threads = coalesce ? 64 : 256;
         src += std::string("typedef ") + ty + " T;\n";
@@ -998,6 +1019,30 @@ bool try_fuse(Plan& plan) {
             };
             if (!coalesce) {
                 src += "  { const T* r = in" + I + " + item * s" + I + ";\n";
+                assign("r", "    ");
+                src += "  }\n";
+                continue;
+            }
+            if (coalesce && by_line[i]) {   // one cache line of every row at a time through the shared buffer
+                const int nblk = int((size_t(len) * esz + 127) / 128);
+                src += "  if (full && ((s" + I + " * " + std::to_string(esz) + ") & 15) == 0 && (((unsigned long long)in" + I + ") & 15ull) == 0) {\n";
+                src += "    T* buf = (T*)(lds + " + std::to_string(line_off) + ");\n";
+                for (int b = 0; b < nblk; ++b) {
+                    const int blk_bytes = int(std::min<size_t>(128, size_t(len) * esz - size_t(128) * b));
+                    const int cpl = blk_bytes / 16, blk_elems = int(blk_bytes / esz), e0 = int(size_t(128) * b / esz);
+                    src += "    { const T* base = in" + I + " + item0 * s" + I + " + " + std::to_string(e0) + " + (lane & 7) * " + std::to_string(epc) + ";\n";
+                    for (int j = 0; j < 8; ++j) src += "      VT c" + std::to_string(j) + ";\n";
+                    src += std::string("      if ((lane & 7) < ") + std::to_string(cpl) + ") {\n";
+                    for (int j = 0; j < 8; ++j)
+                        src += "        c" + std::to_string(j) + " = *(const VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * s" + I + ");\n";
+                    for (int j = 0; j < 8; ++j)
+                        src += "        *(VT*)(buf + (" + std::to_string(8 * j) + " + (lane >> 3)) * " + std::to_string(line_plen) + " + (lane & 7) * " + std::to_string(epc) + ") = c" + std::to_string(j) + ";\n";
+                    src += "      }\n      __syncthreads();\n      const T* r = buf + lane * " + std::to_string(line_plen) + ";\n";
+                    for (int e = 0; e < blk_elems; ++e)
+                        src += "      " + var(uint32_t(fi.base + e0 + e)) + (fi.canon ? " = T(0) + r[" : " = r[") + std::to_string(e) + "];\n";
+                    src += "      __syncthreads();\n    }\n";
+                }
+                src += "  } else if (live) {\n    const T* r = in" + I + " + item * s" + I + ";\n";
                 assign("r", "    ");
                 src += "  }\n";
                 continue;
@@ -1135,6 +1180,24 @@ bool try_fuse(Plan& plan) {
             const int nch = 64 * out_len / epc;
             const int per_lane = (nch + 63) / 64;
             const bool whole = (size_t(out_len) * esz) % 16 == 0;
+            if (out_line) {
+                const int nblk = int((size_t(out_len) * esz + 127) / 128);
+                src += "  if (full && ((so * " + std::to_string(esz) + ") & 15) == 0 && (((unsigned long long)out) & 15ull) == 0) {\n";
+                src += "    T* buf = (T*)(lds + " + std::to_string(line_off) + ");\n";
+                for (int b = 0; b < nblk; ++b) {
+                    const int blk_bytes = int(std::min<size_t>(128, size_t(out_len) * esz - size_t(128) * b));
+                    const int cpl = blk_bytes / 16, blk_elems = int(blk_bytes / esz), e0 = int(size_t(128) * b / esz);
+                    src += "    { __syncthreads();\n      T* r = buf + lane * " + std::to_string(line_plen) + ";\n";
+                    for (int e = 0; e < blk_elems; ++e) src += "      r[" + std::to_string(e) + "] = " + var(uint32_t(out_base + e0 + e)) + ";\n";
+                    src += "      __syncthreads();\n      T* base = out + item0 * so + " + std::to_string(e0) + " + (lane & 7) * " + std::to_string(epc) + ";\n";
+                    src += std::string("      if ((lane & 7) < ") + std::to_string(cpl) + ") {\n";
+                    for (int j = 0; j < 8; ++j)
+                        src += "        *(VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * so) = *(const VT*)(buf + (" + std::to_string(8 * j) +
+                               " + (lane >> 3)) * " + std::to_string(line_plen) + " + (lane & 7) * " + std::to_string(epc) + ");\n";
+                    src += "      }\n    }\n";
+                }
+                src += "  } else\n";
+            }
             src += std::string("  if (") + (out_via_lds ? "full" : "false") + " && so == " + std::to_string(out_len) + " && (((unsigned long long)out) & 15ull) == 0) {\n";
             src += "    __syncthreads();\n    T* img = (T*)lds;\n    { T* r = img + lane * " + std::to_string(plen) + ";\n";
             for (int c = 0; c < out_len; ++c) src += "      r[" + std::to_string(c) + "] = " + var(uint32_t(out_base + c)) + ";\n";
