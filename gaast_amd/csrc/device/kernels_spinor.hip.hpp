@@ -3,6 +3,11 @@
 #pragma once
 #include "kernels_common.hip.hpp"
 
+// build-time A/B switch: compute half of the matrix product and mirror it (real structure of the representation)
+#ifndef GAAST_SPINOR_HALF
+#define GAAST_SPINOR_HALF 1
+#endif
+
 namespace gaast {
 
 // ------------------------------------------------------------------------------------------
@@ -168,6 +173,81 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
         }
         __syncthreads();
 
+        if constexpr (LAMBIT >= 0 && GAAST_SPINOR_HALF) {
+            // ---- 3'. HALF the product.  With lambda != 0 the representation has a real structure:
+            //     M(r ^ lambda, c ^ lambda) = sigma conj(M(r, c)),  sigma = (-1)^(alpha'.(r ^ c))
+            // (both entries are built from the same pair (p, q) of row x = r ^ c, swapped), products inherit it, so only
+            // the 32 rows of C with r_lambda = 0 are computed -- 3 x (32 x 64 x 64) multiply-adds instead of 3 x 64^3 --
+            // and every element also lands, conjugated and signed, at (r ^ lambda, c ^ lambda).  Wave w owns the 32 rows x
+            // columns 16 w .. 16 w + 15 as two 16 x 16 tiles of v_mfma_f32_16x16x4_f32; k = 4 s + kq, k_5 = 0 first.
+            const int i16 = lane & 15, kq = lane >> 4;
+            auto half_row = [](int hr) { return LAMBIT == 5 ? hr : (((hr & 16) << 1) | (hr & 15)); };   // rows with the lambda bit clear
+            float4v gx[2], gy[2], gz[2], bank_re[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx[t][r] = 0.f;
+                    gy[t][r] = 0.f;
+                    gz[t][r] = 0.f;
+                    bank_re[t][r] = 0.f;
+                }
+            {
+                const float* A = smem;
+                const float* B = smem + P;
+                const uint32_t cb = uint32_t(16 * wave + i16);
+                const uint32_t gam = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;       // column bit 5
+#pragma unroll
+                for (int s4 = 0; s4 < 16; ++s4) {
+                    const uint32_t k = uint32_t(4 * s4 + kq);
+                    const bool hi = ((4 * s4) & LAM) != 0;                               // k has the lambda bit: partner below
+                    const uint32_t ib = (cb ^ k) * LD + k;
+                    const float pb = B[ib];
+                    float qb = hi ? B[ib - LAM] : B[ib + LAM];
+                    qb = __uint_as_float(__float_as_uint(qb) ^ gam);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint32_t ra = uint32_t(half_row(16 * t + i16));
+                        const uint32_t rho = (p.has_alpha && (ra >> 5)) ? 0x80000000u : 0u;
+                        const uint32_t ia = (ra ^ k) * LD + k;
+                        const float pa = A[ia];
+                        float qa = hi ? A[ia - LAM] : A[ia + LAM];
+                        qa = __uint_as_float(__float_as_uint(qa) ^ rho);
+                        gx[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, gx[t], 0, 0, 0);
+                        gy[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, gy[t], 0, 0, 0);
+                        gz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, gz[t], 0, 0, 0);
+                    }
+                    if (s4 == 7) {   // real part of the k_5 = 0 half; the accumulators keep running
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                    }
+                }
+            }
+            __syncthreads();  // every wave is done reading the operand planes
+            // ---- 4'. C and its mirror image -> LDS, diagonals indexed by row: S[r ^ c][r] = C[r][c] ----
+            {
+                const int c = 16 * wave + i16;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = half_row(16 * t + 4 * kq + r);      // accumulator layout: row 4 kq + r, column lane & 15
+                        const float re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                        const float re = p.has_alpha ? 2.f * bank_re[t][r] - re_all : re_all;   // first - second half
+                        const float im = gx[t][r] - gy[t][r];
+                        const int x = rr ^ c;
+                        const uint32_t sg = (p.has_alpha && (x >> 5)) ? 0x80000000u : 0u;        // sigma
+                        float* q = smem + x * LD + rr;                     // element (rr, c); (rr ^ lambda, c ^ lambda) shares the row
+                        q[0] = re;
+                        q[P] = im;
+                        q[LAM] = __uint_as_float(__float_as_uint(re) ^ sg);
+                        q[P + LAM] = __uint_as_float(__float_as_uint(im) ^ sg ^ 0x80000000u);
+                    }
+            }
+            __syncthreads();
+        } else {
         // ---- 3. the product: X = p r, Y = q' s', Z = (p+q')(r+s'), k_5 = 0 first ----
         const int i = lane & 31, h = lane >> 5;
         const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
@@ -218,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
             }
         }
         __syncthreads();
+        }
         // ---- 5. four threads per row: fold the plane that holds this quarter's components ----
         {
             constexpr int B1 = LAMBIT == 4 ? 4 : 5, B2 = LAMBIT == 4 ? 5 : 4;   // first fold on the lambda bit
