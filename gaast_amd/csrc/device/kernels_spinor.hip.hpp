@@ -435,6 +435,76 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
         }
         __syncthreads();
 
+        if constexpr (LAMBIT >= 0 && GAAST_SPINOR_HALF) {
+            // ---- 3'. half the product (rows with the lambda bit clear), mirrored: see k_gp_spinor12s.  Wave w owns the 32
+            // rows x columns 16 w .. 16 w + 15 as two 16 x 16 tiles: 6 instead of 12 MFMAs per step of 4 k values ----
+            const int i = lane & 15, kq = lane >> 4;
+            auto half_row = [](int hr) { return LAMBIT == 5 ? hr : (((hr & 16) << 1) | (hr & 15)); };
+            double4v gx[2], gy[2], gz[2], bank_re[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gx[t][r] = 0.0;
+                    gy[t][r] = 0.0;
+                    gz[t][r] = 0.0;
+                    bank_re[t][r] = 0.0;
+                }
+            {
+                const double* A = smem;
+                const double* B = smem + P;
+                const uint32_t cb = uint32_t(16 * wave + i);
+                const uint32_t gam = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;
+                uint32_t kk = uint32_t(kq);
+                asm volatile("" : "+v"(kk));   // addresses are computed per step, not hoisted out of the item loop
+#pragma unroll
+                for (int s4 = 0; s4 < 16; ++s4) {
+                    const uint32_t k = kk;
+                    kk += 4u;
+                    const bool hi = ((4 * s4) & LAM) != 0;
+                    const uint32_t ib = (cb ^ k) * LD + k;
+                    const double pb = B[ib];
+                    const double qb = flip(hi ? B[ib - LAM] : B[ib + LAM], gam);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint32_t ra = uint32_t(half_row(16 * t + i));
+                        const uint32_t ia = (ra ^ k) * LD + k;
+                        const double pa = A[ia];
+                        const double qa = flip(hi ? A[ia - LAM] : A[ia + LAM], (p.has_alpha && (ra >> 5)) ? 0x80000000u : 0u);
+                        gx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, gx[t], 0, 0, 0);
+                        gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, qb, gy[t], 0, 0, 0);
+                        gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa + qa, pb + qb, gz[t], 0, 0, 0);
+                    }
+                    if (s4 == 7) {   // real part of the k_5 = 0 half
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- 4'. C and its mirror image -> LDS; accumulator layout: col = lane & 15, row = (lane >> 4) + 4 r ----
+            {
+                const int c = 16 * wave + i;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = half_row(16 * t + kq + 4 * r);
+                        const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                        const double re = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                        const double im = gx[t][r] - gy[t][r];
+                        const int x = rr ^ c;
+                        const uint32_t sg = (p.has_alpha && (x >> 5)) ? 0x80000000u : 0u;
+                        double* q = smem + x * LD + rr;
+                        q[0] = re;
+                        q[P] = im;
+                        q[LAM] = flip(re, sg);
+                        q[P + LAM] = flip(im, sg ^ 0x80000000u);
+                    }
+            }
+        } else {
         // ---- 3. the product on v_mfma_f64_16x16x4_f64: tiles (rb, cb), X = p r, Y = q' s', Z = (p+q')(r+s') ----
         const int i = lane & 15, kq = lane >> 4;
         const int r0 = (wave >> 1) << 5, c0 = (wave & 1) << 5;
@@ -503,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                     smem[P + (rr ^ c) * LD + rr] = gx[t][r] - gy[t][r];
                 }
             }
+        }
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // the accumulators are dead: room for the rows
         __syncthreads();
         // ---- 5. four threads per row fold the plane that holds this quarter's components ----
@@ -652,6 +723,68 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
         }
         __syncthreads();
 
+        if constexpr (M == 5 && LAMBIT >= 0 && GAAST_SPINOR_HALF) {
+            // half the product (the 16 rows with the lambda bit clear), mirrored: see k_gp_spinor12s.  Two 16 x 16 column
+            // tiles of v_mfma_f32_16x16x4_f32; k = 4 s + kq, the k_top = 0 half first.
+            const int i16 = lane & 15, kq4 = lane >> 4;
+            auto half_row = [](int hr) { return LAMBIT == M - 1 ? hr : (((hr & 8) << 1) | (hr & 7)); };
+            float4v hx[2], hy[2], hz[2], hbank[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hx[t][r] = 0.f;
+                    hy[t][r] = 0.f;
+                    hz[t][r] = 0.f;
+                    hbank[t][r] = 0.f;
+                }
+            const uint32_t ra = uint32_t(half_row(i16));
+            const uint32_t rho = (p.has_alpha && (ra >> (M - 1))) ? 0x80000000u : 0u;
+#pragma unroll
+            for (int s4 = 0; s4 < D / 4; ++s4) {
+                const uint32_t k = uint32_t(4 * s4 + kq4);
+                const bool hi = ((4 * s4) & LAM) != 0;
+                const uint32_t ia = (ra ^ k) * LD + k;
+                const float pa = smem[ia];
+                float qa = hi ? smem[ia - LAM] : smem[ia + LAM];
+                qa = __uint_as_float(__float_as_uint(qa) ^ rho);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t cb = uint32_t(16 * t + i16);
+                    const uint32_t ib = (cb ^ k) * LD + k;
+                    const float pb = smem[P + ib];
+                    float qb = hi ? smem[P + ib - LAM] : smem[P + ib + LAM];
+                    qb = __uint_as_float(__float_as_uint(qb) ^ ((p.has_alpha && t) ? 0x80000000u : 0u));
+                    hx[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, hx[t], 0, 0, 0);
+                    hy[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, hy[t], 0, 0, 0);
+                    hz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, hz[t], 0, 0, 0);
+                }
+                if (s4 == D / 8 - 1) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hbank[t][r] = hz[t][r] - hx[t][r] - hy[t][r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = half_row(4 * kq4 + r), c = 16 * t + i16;      // accumulator: row 4 kq + r, column lane & 15
+                    const float re_all = hz[t][r] - hx[t][r] - hy[t][r];
+                    const float re = p.has_alpha ? 2.f * hbank[t][r] - re_all : re_all;
+                    const float im = hx[t][r] - hy[t][r];
+                    const int x = rr ^ c;
+                    const uint32_t sg = (p.has_alpha && (x >> (M - 1))) ? 0x80000000u : 0u;
+                    float* q = smem + x * LD + rr;
+                    q[0] = re;
+                    q[P] = im;
+                    q[LAM] = __uint_as_float(__float_as_uint(re) ^ sg);
+                    q[P + LAM] = __uint_as_float(__float_as_uint(im) ^ sg ^ 0x80000000u);
+                }
+            __syncthreads();
+        } else {
         acc_t gx, gy, gz, bank_re;
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
@@ -692,6 +825,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
             smem[P + (rr ^ i) * LD + rr] = gx[r] - gy[r];
         }
         __syncthreads();
+        }
         // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
         {
             constexpr int B1 = LAMBIT == M - 2 ? M - 2 : M - 1, B2 = LAMBIT == M - 2 ? M - 1 : M - 2;
@@ -826,6 +960,12 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
         }
         __syncthreads();
 
+        constexpr bool HALF = M == 5 && LAMBIT >= 0 && GAAST_SPINOR_HALF;   // rows with the lambda bit clear, mirrored (k_gp_spinor12s)
+        constexpr int TR = HALF ? 1 : TB;                                    // row tiles
+        auto tile_row = [](int rb, int j) {                                  // row j (0..15) of row tile rb
+            if (!HALF) return 16 * rb + j;
+            return LAMBIT == M - 1 ? j : (((j & 8) << 1) | (j & 7));
+        };
         double4v gx[TB * TB], gy[TB * TB], gz[TB * TB], bank_re[TB * TB];
 #pragma unroll
         for (int t = 0; t < TB * TB; ++t)
@@ -843,19 +983,21 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
             double pa[TB], qa[TB], pb[TB], qb[TB];
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
-                const int rc = 16 * b + i16;                       // row of A / column of B this lane feeds
-                const int idx = (rc ^ k) * LD + k;
-                pa[b] = smem[idx];
-                pb[b] = smem[P + idx];
-                qa[b] = LAMBIT < 0 ? pa[b] : (hi ? smem[idx - LAM] : smem[idx + LAM]);
-                qb[b] = LAMBIT < 0 ? pb[b] : (hi ? smem[P + idx - LAM] : smem[P + idx + LAM]);
-                if (p.has_alpha && (rc >> (M - 1))) {              // sigma of row / column rc
-                    qa[b] = -qa[b];
-                    qb[b] = -qb[b];
+                const int cc = 16 * b + i16;                       // column of B this lane feeds
+                const int ib = (cc ^ k) * LD + k;
+                pb[b] = smem[P + ib];
+                qb[b] = LAMBIT < 0 ? pb[b] : (hi ? smem[P + ib - LAM] : smem[P + ib + LAM]);
+                if (p.has_alpha && (cc >> (M - 1))) qb[b] = -qb[b];   // sigma of column cc
+                if (b < TR) {
+                    const int rc = tile_row(b, i16);               // row of A this lane feeds
+                    const int ia = (rc ^ k) * LD + k;
+                    pa[b] = smem[ia];
+                    qa[b] = LAMBIT < 0 ? pa[b] : (hi ? smem[ia - LAM] : smem[ia + LAM]);
+                    if (p.has_alpha && (rc >> (M - 1))) qa[b] = -qa[b];   // sigma of row rc
                 }
             }
 #pragma unroll
-            for (int rb = 0; rb < TB; ++rb)
+            for (int rb = 0; rb < TR; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < TB; ++cb) {
                     const int t = rb * TB + cb;
@@ -872,17 +1014,25 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int rb = 0; rb < TB; ++rb)
+        for (int rb = 0; rb < TR; ++rb)
 #pragma unroll
             for (int cb = 0; cb < TB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = rb * TB + cb;
                     // accumulator layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 r
-                    const int rr = 16 * rb + kq + 4 * r, cc = 16 * cb + i16;     // element (row rr, column cc) of the product
+                    const int rr = tile_row(rb, kq + 4 * r), cc = 16 * cb + i16;     // element (row rr, column cc) of the product
                     const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
-                    smem[(rr ^ cc) * LD + rr] = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
-                    smem[P + (rr ^ cc) * LD + rr] = gx[t][r] - gy[t][r];
+                    const double re = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                    const double im = gx[t][r] - gy[t][r];
+                    double* q = smem + (rr ^ cc) * LD + rr;
+                    q[0] = re;
+                    q[P] = im;
+                    if (HALF) {   // the mirror image (rr ^ lambda, cc ^ lambda): same row of S, conjugated, times sigma
+                        const bool neg = p.has_alpha && (((rr ^ cc) >> (M - 1)) & 1);
+                        q[LAM] = neg ? -re : re;
+                        q[P + LAM] = neg ? im : -im;
+                    }
                 }
         __syncthreads();
         // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
