@@ -49,6 +49,14 @@ def workload_spec(name):
                     build=lambda a, b: a * b, entries=4 ** n, default_batch=65536, flags=ga.FLAG_SPINOR_GEMM,
                     flops_item=2 * 3 * 64 ** 3 + 2 * 384 * (256 + 64),
                     label="R^12 full MV x MV geometric product, f32, opt-in 64x64 complex matrix representation")
+    if name == "r66s":
+        # Cl(6,6) = M(64, R): the matrix representation is real (lambda = 0), one real 64 x 64 product per item
+        n = 12
+        full = list(range(n + 1))
+        return dict(n=n, metric=[1.0, -1.0] * 6, dtype=ga.F32, dtname="f32", inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=65536, flags=ga.FLAG_SPINOR_GEMM,
+                    flops_item=2 * 64 ** 3 + 2 * 384 * (256 + 64),
+                    label="Cl(6,6) full MV x MV geometric product, f32, opt-in 64x64 REAL matrix representation")
     if name == "r12d":
         n = 12
         full = list(range(n + 1))

@@ -61,6 +61,25 @@ struct SpinorArgs {
     int64_t batch;
 };
 
+// lambda = 0 (LAMBIT < 0): q = +-p, every entry of the representation matrix is real or purely imaginary, and Y and Z
+// are multiples of X = p r: ONE real product instead of three.  From X (all of k) and X1 (the k_top = 0 half), the
+// signs rho / gam of the element's row / column (true = -1): what the three-product code stores as (Z - X - Y with the
+// second half subtracted, X - Y).
+template <typename T>
+__device__ __forceinline__ void real_case_planes(T X, T X1, bool has_alpha, bool rho, bool gam, T* re, T* im) {
+    if (!has_alpha) {
+        *re = T(2) * X;
+        *im = T(0);
+    } else if (rho == gam) {
+        const T d = T(2) * (T(2) * X1 - X);
+        *re = rho ? -d : d;
+        *im = T(0);
+    } else {
+        *re = T(0);
+        *im = T(2) * X;
+    }
+}
+
 template <int N, typename T = float>
 __device__ __forceinline__ void wht(T (&v)[N]) {
 #pragma unroll
@@ -276,11 +295,13 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 qa = __uint_as_float(__float_as_uint(qa) ^ rho_mask);
                 qb = __uint_as_float(__float_as_uint(qb) ^ gam_mask);
                 gx = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, pb, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                if constexpr (LAMBIT >= 0) {
+                    gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
+                    gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                }
                 if (s2 == 15) {   // real part of the k_5 = 0 half; the accumulators keep running
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) bank_re[r] = gz[r] - gx[r] - gy[r];
+                    for (int r = 0; r < 16; ++r) bank_re[r] = LAMBIT >= 0 ? gz[r] - gx[r] - gy[r] : gx[r];
                 }
             }
         }
@@ -292,9 +313,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float re_all = gz[r] - gx[r] - gy[r];            // both halves added
-                smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;   // first - second
-                smem[P + (rr ^ c) * LD + rr] = gx[r] - gy[r];
+                if constexpr (LAMBIT < 0) {
+                    float re, im;
+                    real_case_planes<float>(gx[r], bank_re[r], p.has_alpha, rho_mask != 0, gam_mask != 0, &re, &im);
+                    smem[(rr ^ c) * LD + rr] = re;
+                    smem[P + (rr ^ c) * LD + rr] = im;
+                } else {
+                    const float re_all = gz[r] - gx[r] - gy[r];            // both halves added
+                    smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;   // first - second
+                    smem[P + (rr ^ c) * LD + rr] = gx[r] - gy[r];
+                }
             }
         }
         __syncthreads();
@@ -545,14 +573,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                     for (int cbk = 0; cbk < 2; ++cbk) {
                         const int t = rb * 2 + cbk;
                         gx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb], pb[cbk], gx[t], 0, 0, 0);
-                        gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cbk], gy[t], 0, 0, 0);
-                        gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cbk] + qb[cbk], gz[t], 0, 0, 0);
+                        if constexpr (LAMBIT >= 0) {
+                            gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cbk], gy[t], 0, 0, 0);
+                            gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cbk] + qb[cbk], gz[t], 0, 0, 0);
+                        }
                     }
                 if (s4 == 7) {   // real part of the k_5 = 0 half
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                        for (int r = 0; r < 4; ++r) bank_re[t][r] = LAMBIT >= 0 ? gz[t][r] - gx[t][r] - gy[t][r] : gx[t][r];
                 }
             }
         }
@@ -568,9 +598,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = r0 + 16 * rb + kq + 4 * r;
-                    const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
-                    smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
-                    smem[P + (rr ^ c) * LD + rr] = gx[t][r] - gy[t][r];
+                    if constexpr (LAMBIT < 0) {
+                        double re, im;
+                        real_case_planes<double>(gx[t][r], bank_re[t][r], p.has_alpha, rho_mask != 0, gam_mask != 0, &re, &im);
+                        smem[(rr ^ c) * LD + rr] = re;
+                        smem[P + (rr ^ c) * LD + rr] = im;
+                    } else {
+                        const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                        smem[(rr ^ c) * LD + rr] = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                        smem[P + (rr ^ c) * LD + rr] = gx[t][r] - gy[t][r];
+                    }
                 }
             }
         }
@@ -804,25 +841,36 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
             qb = __uint_as_float(__float_as_uint(qb) ^ sig_mask);
             if constexpr (M == 4) {
                 gx = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                if constexpr (LAMBIT >= 0) {
+                    gy = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, gy, 0, 0, 0);
+                    gz = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                }
             } else {
                 gx = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, pb, gx, 0, 0, 0);
-                gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
-                gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                if constexpr (LAMBIT >= 0) {
+                    gy = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, qb, gy, 0, 0, 0);
+                    gz = __builtin_amdgcn_mfma_f32_32x32x2f32(pa + qa, pb + qb, gz, 0, 0, 0);
+                }
             }
             if (s2 == NSTEPS / 2 - 1) {   // k_top = 0 half done
 #pragma unroll
-                for (int r = 0; r < NACC; ++r) bank_re[r] = gz[r] - gx[r] - gy[r];
+                for (int r = 0; r < NACC; ++r) bank_re[r] = LAMBIT >= 0 ? gz[r] - gx[r] - gy[r] : gx[r];
             }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
-            const float re_all = gz[r] - gx[r] - gy[r];
-            smem[(rr ^ i) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;
-            smem[P + (rr ^ i) * LD + rr] = gx[r] - gy[r];
+            if constexpr (LAMBIT < 0) {
+                float re, im;
+                real_case_planes<float>(gx[r], bank_re[r], p.has_alpha, (rr >> (M - 1)) != 0, (i >> (M - 1)) != 0, &re, &im);
+                smem[(rr ^ i) * LD + rr] = re;
+                smem[P + (rr ^ i) * LD + rr] = im;
+            } else {
+                const float re_all = gz[r] - gx[r] - gy[r];
+                smem[(rr ^ i) * LD + rr] = p.has_alpha ? 2.f * bank_re[r] - re_all : re_all;
+                smem[P + (rr ^ i) * LD + rr] = gx[r] - gy[r];
+            }
         }
         __syncthreads();
         }
@@ -1002,14 +1050,16 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 for (int cb = 0; cb < TB; ++cb) {
                     const int t = rb * TB + cb;
                     gx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb], pb[cb], gx[t], 0, 0, 0);
-                    gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cb], gy[t], 0, 0, 0);
-                    gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cb] + qb[cb], gz[t], 0, 0, 0);
+                    if constexpr (LAMBIT >= 0) {
+                        gy[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[rb], qb[cb], gy[t], 0, 0, 0);
+                        gz[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[rb] + qa[rb], pb[cb] + qb[cb], gz[t], 0, 0, 0);
+                    }
                 }
             if (s2 == NSTEPS / 2 - 1) {   // k_top = 0 half done
 #pragma unroll
                 for (int t = 0; t < TB * TB; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                    for (int r = 0; r < 4; ++r) bank_re[t][r] = LAMBIT >= 0 ? gz[t][r] - gx[t][r] - gy[t][r] : gx[t][r];
             }
         }
         __syncthreads();
@@ -1022,9 +1072,14 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                     const int t = rb * TB + cb;
                     // accumulator layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 r
                     const int rr = tile_row(rb, kq + 4 * r), cc = 16 * cb + i16;     // element (row rr, column cc) of the product
-                    const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
-                    const double re = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
-                    const double im = gx[t][r] - gy[t][r];
+                    double re, im;
+                    if constexpr (LAMBIT < 0) {
+                        real_case_planes<double>(gx[t][r], bank_re[t][r], p.has_alpha, (rr >> (M - 1)) != 0, (cc >> (M - 1)) != 0, &re, &im);
+                    } else {
+                        const double re_all = gz[t][r] - gx[t][r] - gy[t][r];
+                        re = p.has_alpha ? 2.0 * bank_re[t][r] - re_all : re_all;
+                        im = gx[t][r] - gy[t][r];
+                    }
                     double* q = smem + (rr ^ cc) * LD + rr;
                     q[0] = re;
                     q[P] = im;

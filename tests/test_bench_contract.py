@@ -7,7 +7,7 @@ import pytest
 import bench
 
 
-@pytest.mark.parametrize("name", ["r12", "r12s", "r12d", "r12ds", "r12x", "r8", "r8d", "r8s", "r8x", "cl41", "cl41g1", "cl41s",
+@pytest.mark.parametrize("name", ["r12", "r12s", "r66s", "r12d", "r12ds", "r12x", "r8", "r8d", "r8s", "r8x", "cl41", "cl41g1", "cl41s",
                                   "gp6f32", "gp10f64", "gp9f32s", "gp8f64x"])
 def test_workloads_resolve(name):
     wl = bench.workload_spec(name)
