@@ -61,6 +61,9 @@ struct SpinorArgs {
     int64_t batch;
 };
 
+__device__ __forceinline__ float fma_x(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_x(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // lambda = 0 (LAMBIT < 0): q = +-p, every entry of the representation matrix is real or purely imaginary, and Y and Z
 // are multiples of X = p r: ONE real product instead of three.  From X (all of k) and X1 (the k_top = 0 half), the
 // signs rho / gam of the element's row / column (true = -1): what the three-product code stores as (Z - X - Y with the
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
             const float sg = hb ? -1.f : 1.f;
             float v[32];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = row[c] + row[c + 32] * sg;
+            for (int c = 0; c < 32; ++c) v[c] = fma_x(row[c + 32], sg, row[c]);   // sg = +-1: an exact product, one instruction
             wht<32>(v);
 #pragma unroll
             for (int c = 0; c < 32; ++c) row[c + 32 * hb] = v[c];   // the partner (adjacent lane) has read already
@@ -339,9 +342,10 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
             float v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float lo = q[j] * sc + q[j | (1 << B1)] * s1;
-                const float hi = q[j | (1 << B2)] * sc + q[j | (1 << B1) | (1 << B2)] * s1;
-                v[j] = lo + hi * s2f;
+                // sc, s1 = +-2^-7, s2f = +-1: every product is exact, the fused forms round like the unfused ones
+                const float lo = fma_x(q[j | (1 << B1)], s1, q[j] * sc);
+                const float hi = fma_x(q[j | (1 << B1) | (1 << B2)], s1, q[j | (1 << B2)] * sc);
+                v[j] = fma_x(hi, s2f, lo);
             }
             wht<16>(v);
             float* o = smem + x * LD + (h1 << B1) + (h2 << B2);
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
             const double sg = hb ? -1.0 : 1.0;
             double v[32];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = row[c] + row[c + 32] * sg;
+            for (int c = 0; c < 32; ++c) v[c] = fma_x(row[c + 32], sg, row[c]);   // sg = +-1: an exact product, one instruction
 #pragma unroll
             for (int hlf = 1; hlf < 32; hlf <<= 1) {
 #pragma unroll
@@ -625,9 +629,10 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
             double v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double lo = q[j] * sc + q[j | (1 << B1)] * s1;
-                const double hi = q[j | (1 << B2)] * sc + q[j | (1 << B1) | (1 << B2)] * s1;
-                v[j] = lo + hi * s2f;
+                // sc, s1 = +-2^-7, s2f = +-1: every product is exact, the fused forms round like the unfused ones
+                const double lo = fma_x(q[j | (1 << B1)], s1, q[j] * sc);
+                const double hi = fma_x(q[j | (1 << B1) | (1 << B2)], s1, q[j | (1 << B2)] * sc);
+                v[j] = fma_x(hi, s2f, lo);
             }
 #pragma unroll
             for (int hlf = 1; hlf < 16; hlf <<= 1) {
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
             const float sg = hb ? -1.f : 1.f;
             float v[D / 2];
 #pragma unroll
-            for (int c = 0; c < D / 2; ++c) v[c] = row[c] + row[c + D / 2] * sg;
+            for (int c = 0; c < D / 2; ++c) v[c] = fma_x(row[c + D / 2], sg, row[c]);   // sg = +-1: an exact product, one instruction
             wht<D / 2>(v);
 #pragma unroll
             for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
@@ -890,9 +895,10 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 const float s1 = h1 ? -sc : sc, s2f = h2 ? -1.f : 1.f;
 #pragma unroll
                 for (int c = 0; c < Q; ++c) {
-                    const float lo = q[c] * sc + q[c | (1 << B1)] * s1;
-                    const float up = q[c | (1 << B2)] * sc + q[c | (1 << B1) | (1 << B2)] * s1;
-                    v[j][c] = lo + up * s2f;
+                    // sc, s1 = +-2^-k, s2f = +-1: every product is exact, the fused forms round like the unfused ones
+                    const float lo = fma_x(q[c | (1 << B1)], s1, q[c] * sc);
+                    const float up = fma_x(q[c | (1 << B1) | (1 << B2)], s1, q[c | (1 << B2)] * sc);
+                    v[j][c] = fma_x(up, s2f, lo);
                 }
                 wht<Q>(v[j]);
             }
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
             const double sg = hb ? -1.0 : 1.0;
             double v[D / 2];
 #pragma unroll
-            for (int c = 0; c < D / 2; ++c) v[c] = row[c] + row[c + D / 2] * sg;
+            for (int c = 0; c < D / 2; ++c) v[c] = fma_x(row[c + D / 2], sg, row[c]);   // sg = +-1: an exact product, one instruction
             wht<D / 2, double>(v);
 #pragma unroll
             for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
@@ -1106,9 +1112,10 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 const double s1 = h1 ? -sc : sc, s2f = h2 ? -1.0 : 1.0;
 #pragma unroll
                 for (int c = 0; c < Q; ++c) {
-                    const double lo = q[c] * sc + q[c | (1 << B1)] * s1;
-                    const double up = q[c | (1 << B2)] * sc + q[c | (1 << B1) | (1 << B2)] * s1;
-                    v[j][c] = lo + up * s2f;
+                    // sc, s1 = +-2^-k, s2f = +-1: every product is exact, the fused forms round like the unfused ones
+                    const double lo = fma_x(q[c | (1 << B1)], s1, q[c] * sc);
+                    const double up = fma_x(q[c | (1 << B1) | (1 << B2)], s1, q[c | (1 << B2)] * sc);
+                    v[j][c] = fma_x(up, s2f, lo);
                 }
                 wht<Q, double>(v[j]);
             }
