@@ -13,6 +13,11 @@
 #ifndef GAAST_DENSE_NO_CANON
 #define GAAST_DENSE_NO_CANON 0
 #endif
+// k_gp_mfma16: keep a NEGATED copy of the B image in LDS and pick the image by the block sign (one address term per step
+// instead of 16 sign flips)
+#ifndef GAAST_MFMA16_NEGB
+#define GAAST_MFMA16_NEGB 0
+#endif
 #ifndef GAAST_MFMA16_SETPRIO
 #define GAAST_MFMA16_SETPRIO 1
 #endif
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
     constexpr int H = 1 << (n - 4);               // number of 16-blocks
     constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
     constexpr int IPB = 4;                        // items per workgroup pass: the four blocks of the instruction
-    constexpr int item_stride = 2 * N + 16;
+    constexpr int item_stride = (GAAST_MFMA16_NEGB ? 3 : 2) * N + 16;   // A image, B image[, -B image]
     constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row == THREADS: thread t moves piece t of every row
     static_assert(COUNT4 == THREADS, "one 16-byte piece of each row per thread");
     const int tid = threadIdx.x;
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             }
         }
     };
-    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon) {
+    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon, bool with_negative) {
         const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -677,6 +682,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #endif
             y = __uint_as_float(__float_as_uint(y) ^ sg[c]);
             *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * item_stride * 4)) = y;
+            if (with_negative) *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * item_stride * 4 + N * 4)) = -y;
         }
     };
     if (FAST && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
@@ -741,8 +747,8 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #pragma unroll
             for (int k = 0; k < IPB; ++k) {
                 if (k < nitems) {
-                    scatter4(k, pf_l[k], wa, sa, p.canon_left);
-                    scatter4(k, pf_r[k], wb, sb, p.canon_right);
+                    scatter4(k, pf_l[k], wa, sa, p.canon_left, false);
+                    scatter4(k, pf_r[k], wb, sb, p.canon_right, GAAST_MFMA16_NEGB != 0);
                 }
             }
         } else {
@@ -754,6 +760,13 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
                                            p.canon_left, smem, item_stride, nitems, tid);
             stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
                                            p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+#if GAAST_MFMA16_NEGB
+            __syncthreads();
+            for (int e = tid; e < nitems * N; e += THREADS) {
+                const int sit = e / N, j = e - sit * N;
+                smem[sit * item_stride + 2 * N + j] = -smem[sit * item_stride + N + j];
+            }
+#endif
         }
         __syncthreads();   // one wave at n = 8: no wait
         if (FAST && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
@@ -774,9 +787,14 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #endif
             const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
             uint32_t bw[16];
+#if GAAST_MFMA16_NEGB
+            const unsigned char* Bsel = Bs_b + (sbit ? uint32_t(N * 4) : 0u);     // the lane's B block from the image of its sign
+#else
+            const unsigned char* Bsel = Bs_b;
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint4 v = *reinterpret_cast<const uint4*>(Bs_b + (bq[q] ^ sx));
+                const uint4 v = *reinterpret_cast<const uint4*>(Bsel + (bq[q] ^ sx));
                 bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
             }
             const uint32_t w0 = As_own[a_hi << 4];
@@ -789,6 +807,10 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
                 const float2v bp2 = float2v{__uint_as_float(bw[k & ~1]), __uint_as_float(bw[k | 1])} * sgn2;
                 const float bf = (k & 1) ? bp2.y : bp2.x;
                 acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, bf, acc, 0, 0, 0);
+#elif GAAST_MFMA16_NEGB
+                uint32_t b = bw[k];
+                if (DEGENERATE) b &= keep;
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, __uint_as_float(b), acc, 0, 0, 0);
 #else
                 uint32_t b = bw[k] ^ sbit;
                 if (DEGENERATE) b &= keep;

@@ -247,7 +247,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             if constexpr (!is_f64) {
                 s.threads = 64 << (n - 8);                     // one wave per 16 result columns of a group of four items
                 s.items_per_block = 4;
-                s.lds = size_t(4) * size_t((2 << n) + 16) * sizeof(float);
+                s.lds = size_t(4) * size_t((GAAST_MFMA16_NEGB ? 3 : 2) * (size_t(1) << n) + 16) * sizeof(float);   // A, B[, -B] images of four items
                 // [0]: general staging; [1]: register prefetch, when both operands are full rows that turn out
                 // contiguous and 16-byte aligned at launch
                 using KernD = void (*)(DenseArgs<float>);
