@@ -404,7 +404,7 @@ struct Lowering {
     int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
         const int n = d.vec_space_dim;
-        if (n < 6 || n > 13) return 0;  // small algebras: the exact kernel is HBM-bound anyway
+        if (n < 6 || n > 14) return 0;  // small algebras: the exact kernel is HBM-bound anyway
         if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return 0;
         for (int i = 0; i < n; ++i) {
             const double g = d.metric_diag[i];
@@ -416,6 +416,7 @@ struct Lowering {
         const bool mfma_ok = plan.dtype == GAAST_F32 && !(plan.flags & GAAST_FLAG_NO_MFMA);
         // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (four items per wave)
         if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
+        if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
         if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
         if (dense_basis_permutation(4, true, perm)) return 1;
         return 0;

@@ -237,8 +237,9 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 s.items_per_block = (s.threads / 64) / wpi;
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
-                auto kern = s.threads == 256 ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
-                                             : (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>);
+                auto kern = s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
+                            : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>)
+                                               : (s.degenerate ? &k_gp_mfma32<true, 1024> : &k_gp_mfma32<false, 1024>);   // n = 14: 16 waves, 128 KiB of LDS
                 s.kern[0] = reinterpret_cast<const void*>(kern);
                 return allow_lds(s.kern[0], s.lds);
             }

@@ -186,7 +186,7 @@ int main() {
         lower(e, 5, cga, GAAST_F64, 0, "cfg5 sandwich", "ast_");
         lower(e, 5, cga, GAAST_F32, GAAST_FLAG_NO_JIT, "cfg5 sandwich f32", "ast_");
     }
-    for (int n : {6, 7, 8, 9, 10, 11, 12, 13}) {   // dense products: vector / matrix-core / matrix-representation tables
+    for (int n : {6, 7, 8, 9, 10, 11, 12, 13, 14}) {   // dense products (n = 14: matrix-core kernel only, f32): vector / matrix-core / matrix-representation tables
         gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
         gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
         char what[64];

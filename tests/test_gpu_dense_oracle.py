@@ -107,3 +107,55 @@ def test_dense_kernels_need_enough_non_null_vectors():
     got, _, spec = hip_eval_batch(build, metric, rows, batch)
     assert not any("product_dense" in l for l in spec.launches()), spec.launches()
     assert np.array_equal(got, want)
+
+
+def test_n14_sixteen_waves_per_item_against_a_sparse_left_operand():
+    """k_gp_mfma32<false, 1024>: n = 14 (16,384 components, 128 KiB of LDS per item, 16 waves).  The reference's table
+    would be 15 GB, so the check is the bitmask form C[a ^ b] += s(a, b) A[a] B[b] with a SPARSE left operand (48 non-zero
+    components spread over all grades) and a dense right one -- every output component, every block sign -- plus basis
+    blades exactly.  Mixed signature: -1 among lo and hi bits."""
+    from helpers import _POP16, blades_in_row_order
+    n, N, batch = 14, 1 << 14, 2
+    metric = [1.0, -1.0, 1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0]
+    rng = np.random.default_rng(14)
+    blades = blades_in_row_order(n, full_grades(n))
+    pos_of = np.zeros(N, dtype=np.int64)
+    pos_of[blades] = np.arange(N)
+    A = np.zeros((batch, N), np.float32)
+    nz = [rng.choice(N, 48, replace=False) for _ in range(batch)]
+    for i in range(batch):
+        A[i, nz[i]] = rng.uniform(-1, 1, 48).astype(np.float32)
+    B = rng.uniform(-1, 1, (batch, N)).astype(np.float32)
+    build, _ = _gp(n)
+    got, mask, spec = hip_eval_batch(build, metric, {0: A, 1: B}, batch, dtype=ga.F32)
+    assert any(l.startswith("product_dense_mfma[gp n=14") for l in spec.launches()), spec.launches()
+    neg = sum(1 << i for i, g in enumerate(metric) if g < 0)
+    bmask = np.arange(N, dtype=np.int64)
+    for i in range(batch):
+        want = np.zeros(N)
+        absum = np.zeros(N)
+        Bbits = np.zeros(N)
+        Bbits[blades] = B[i].astype(np.float64)
+        for p in nz[i]:
+            a = int(blades[p])
+            par = np.zeros(N, dtype=np.int64)
+            for sft in range(1, n):
+                par += _POP16[(a >> sft) & bmask]
+            par += _POP16[a & bmask & neg]
+            term = np.where(par & 1, -1.0, 1.0) * float(A[i, p]) * Bbits
+            np.add.at(want, a ^ bmask, term)
+            np.add.at(absum, a ^ bmask, np.abs(term))
+        err = np.abs(got[i].astype(np.float64) - want[blades])
+        assert np.all(err <= 4 * 2.0 ** -23 * absum[blades] + 1e-30), float((err / (4 * 2.0 ** -23 * absum[blades] + 1e-30)).max())
+    # basis blades: e_S e_T = +- e_{S ^ T}, exactly
+    a_idx, b_idx = rng.integers(0, N, 8), rng.integers(0, N, 8)
+    ra, rb = np.zeros((8, N), np.float32), np.zeros((8, N), np.float32)
+    ra[np.arange(8), a_idx] = 1.0
+    rb[np.arange(8), b_idx] = 1.0
+    got, _, _ = hip_eval_batch(build, metric, {0: ra, 1: rb}, 8, dtype=ga.F32)
+    alg = ga.MetricAlgebra(metric)
+    for i in range(8):
+        res, coeff = alg.ortho_basis_blades_gp(int(blades[a_idx[i]]), int(blades[b_idx[i]]))
+        want = np.zeros(N, np.float32)
+        want[pos_of[res]] = coeff
+        assert np.array_equal(got[i], want), i
