@@ -7,6 +7,9 @@
 #ifndef GAAST_MFMA32_DPP
 #define GAAST_MFMA32_DPP 0
 #endif
+#ifndef GAAST_MFMA32_LEAN      /* k_gp_mfma32: B addresses as (lane constant) ^ (step constant), block sign in three instructions */
+#define GAAST_MFMA32_LEAN 1
+#endif
 #ifndef GAAST_MFMA16_BSIGN_MUL
 #define GAAST_MFMA16_BSIGN_MUL 0
 #endif
@@ -562,6 +565,15 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
+#if GAAST_MFMA32_LEAN
+        // lane constants of the B side: byte offset of logical quad q of the lane's block, (lane constant) ^ (step constant)
+        // as in k_gp_mfma16; c_hi with a spare bit set, so that the uniform part u of the block sign rides in the popcount
+        const unsigned char* Bs_b = reinterpret_cast<const unsigned char*>(Bs);
+        uint32_t bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = (uint32_t(c_hi) << 7) | (uint32_t((((h << 2) | q) ^ (c_hi >> 1)) & 7) << 4);
+        const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
+#endif
         auto one_step = [&](int a_hi) {
             // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
             uint32_t sp = uint32_t(a_hi) >> 1;
@@ -572,20 +584,33 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
             const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
             const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
                                 __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+#if GAAST_MFMA32_LEAN
+            const uint32_t bmask = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) << 31;
+#else
             const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
+#endif
             float bscale = 1.f;
             if (DEGENERATE) {
                 if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
             }
+            float bv[16];
+#if GAAST_MFMA32_LEAN
+            const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v v = *reinterpret_cast<const float4v*>(Bs_b + (bq[q] ^ sx));
+                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+            }
+#else
             const int x = a_hi ^ c_hi;
             const int rot = (x >> 1) & 7;
             const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 5));
-            float bv[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4v v = bp[((h << 2) | q) ^ rot];
                 bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
             }
+#endif
             const uint32_t abase = uint32_t(a_hi) << 7;
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
