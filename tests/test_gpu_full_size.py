@@ -156,3 +156,42 @@ def test_cl41_identity_rotor_sandwich_at_full_batch():
     want, omask = oracle_eval_batch(build, metric, rows, len(idx))
     assert omask == out_mask
     assert np.array_equal(out_t[idx].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n", [12, 8])
+def test_scaling_and_sign_symmetries_hold_bit_for_bit_at_full_batch(n):
+    """Properties the dense kernels must keep EXACTLY whatever their summation order, at the BASELINE batch, every
+    component of every item: (2^k A) B = 2^k (A B) (scaling by a power of two commutes with every rounding),
+    (-A) B = -(A B) = A (-B) (rounding is symmetric), and the same for a different power on the right operand."""
+    batch, N = FULL[n], 1 << n
+    spec = _spec(n, 0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77 + n)
+    ta = torch.rand((batch, N), generator=gen, device="cuda", dtype=torch.float32) * 2 - 1
+    tb = torch.rand((batch, N), generator=gen, device="cuda", dtype=torch.float32) * 2 - 1
+    base = _run(spec, n, ta, tb).clone()
+    assert torch.equal(_run(spec, n, ta * 8.0, tb), base * 8.0)
+    assert torch.equal(_run(spec, n, ta, tb * 0.25), base * 0.25)
+    assert torch.equal(_run(spec, n, -ta, tb), -base)
+    assert torch.equal(_run(spec, n, ta, -tb), -base)
+    # ... and a checksum over the whole batch that changes if any item is mixed up with another: item i scaled by 2^(i % 5)
+    scale = (2.0 ** (torch.arange(batch, device="cuda") % 5)).to(torch.float32).unsqueeze(1)
+    assert torch.equal(_run(spec, n, ta * scale, tb), base * scale)
+
+
+def test_linearity_in_the_left_operand_at_full_batch():
+    """(A + A') B = A B + A' B to the dense tolerance, every component of every item of the R^12 batch; the bound is
+    4 eps of the sum of |terms| bounded from above by |A|_1-type norms, here simply checked against the products'
+    own magnitudes: |(A + A') B - A B - A' B| <= 16 eps * 4096 * max|A| max|B|."""
+    n, batch, N = 12, FULL[12], 4096
+    spec = _spec(n, 0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    ta = torch.rand((batch, N), generator=gen, device="cuda", dtype=torch.float32) * 2 - 1
+    ta2 = torch.rand((batch, N), generator=gen, device="cuda", dtype=torch.float32) * 2 - 1
+    tb = torch.rand((batch, N), generator=gen, device="cuda", dtype=torch.float32) * 2 - 1
+    lhs = _run(spec, n, ta + ta2, tb).clone()
+    rhs = _run(spec, n, ta, tb).clone()
+    rhs += _run(spec, n, ta2, tb)
+    err = (lhs.double() - rhs.double()).abs().max().item()
+    assert err <= 16 * 2.0 ** -23 * 4096 * 2.0, err
