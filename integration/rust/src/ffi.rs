@@ -24,6 +24,7 @@ pub const OP_SSQRT: i32 = 10;
 
 pub const FLAG_EXACT_ORDER: u32 = 0x4; // bit-exact f64 sums even for dense products
 pub const FLAG_SPINOR_GEMM: u32 = 0x20; // opt-in matrix-representation products (norm-wise error bound)
+pub const FLAG_EXP_LOG: u32 = 0x100; // opt-in extension: evaluate Exponential / Logarithm (todo!() upstream, eval.rs:112-113)
 
 #[repr(C)]
 pub struct GaastCompMul {
@@ -100,6 +101,7 @@ extern "C" {
     pub fn gaast_hip_program_create(desc: *const GaastProgramDesc, out: *mut Program) -> c_int;
     pub fn gaast_hip_program_destroy(p: Program) -> c_int;
     pub fn gaast_hip_program_output_info(p: Program, mask: *mut u64, row_len: *mut i64) -> c_int;
+    pub fn gaast_hip_program_domain_errors(p: Program, count: *mut i64) -> c_int;
     pub fn gaast_hip_mv_alloc(dim: c_int, mask: u64, batch: i64, dtype: c_int, out: *mut Mv) -> c_int;
     pub fn gaast_hip_mv_free(m: Mv) -> c_int;
     pub fn gaast_hip_mv_upload(m: Mv, grade: c_int, host: *const c_void, count: i64) -> c_int;
