@@ -307,3 +307,56 @@ def test_eval_gather_chunk_schedule_on_a_one_rank_communicator():
         _lib.check(L.gaast_hip_comm_destroy())
     r, w = C.c_int(), C.c_int()
     assert L.gaast_hip_comm_info(C.byref(r), C.byref(w)) == 5
+
+
+@pytest.mark.parametrize("case", ["cl41_span", "r5_lines"])
+@pytest.mark.parametrize("layout", ["contiguous", "strided_aligned", "strided_odd", "misaligned_base"])
+def test_specialised_kernels_row_io_forms_are_bit_exact(case, layout):
+    """The hiprtc kernels pick their row I/O per operand at run time: one coalesced span through LDS (contiguous, 16-byte
+    aligned rows), a cache line of every row at a time (long rows; any 16-byte-multiple stride), or every lane its own row
+    (odd strides, misaligned bases, the last partial wave).  Same bits in every form; the batch ends in a partial wave."""
+    import torch
+    ga.init_device()
+    batch = 64 * 5 + 37
+    rng = np.random.default_rng(31)
+    if case == "cl41_span":
+        n, alg = 5, [1.0, 1.0, 1.0, 1.0, -1.0]
+        grades = [[0, 2, 4], [1]]
+        build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, [0, 2, 4], n), B.input(1, [1], n))
+        flags = 0
+    else:
+        n, alg = 5, 5
+        grades = [full_grades(5), full_grades(5)]
+        build = lambda B: B.input(0, full_grades(n), n) * B.input(1, full_grades(n), n)
+        flags = ga.FLAG_EXACT_ORDER
+    rows = {s: rows_of(n, g, batch, rng) for s, g in enumerate(grades)}
+    want, wmask = oracle_eval_batch(build, alg, rows, batch)
+    spec = build(HipBackend()).specialize(alg, flags=flags)
+    assert any("ast_jit" in l for l in spec.launches()), spec.launches()
+    pad = {"contiguous": 0, "strided_aligned": 6, "strided_odd": 3, "misaligned_base": 0}[layout]   # doubles of padding per row
+    shift = 1 if layout == "misaligned_base" else 0                                                  # base pointer off by 8 bytes
+    keep, ins = [], []
+    for s, g in enumerate(grades):
+        rl = rows[s].shape[1]
+        flat = torch.full((batch * (rl + pad) + 2,), 777.0, dtype=torch.float64, device="cuda")
+        view = flat[shift:shift + batch * (rl + pad)].view(batch, rl + pad)
+        view[:, :rl] = torch.from_numpy(rows[s]).cuda()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().gaast_hip_mv_wrap(C.c_void_p(view.data_ptr()), n, ga.graded._mask_of(g), batch, _lib.F64, rl + pad, C.byref(h)))
+        keep.append((flat, view))
+        ins.append(h)
+    orl = want.shape[1]
+    oflat = torch.full((batch * (orl + pad) + 2,), -5.0, dtype=torch.float64, device="cuda")
+    oview = oflat[shift:shift + batch * (orl + pad)].view(batch, orl + pad)
+    ho = C.c_void_p()
+    _lib.check(_lib.lib().gaast_hip_mv_wrap(C.c_void_p(oview.data_ptr()), n, wmask, batch, _lib.F64, orl + pad, C.byref(ho)))
+    handles = (C.c_void_p * 2)(*ins)
+    _lib.check(_lib.lib().gaast_hip_eval(spec.program(), handles, 2, batch, ho))
+    _lib.check(_lib.lib().gaast_hip_synchronize())
+    got = oview[:, :orl].cpu().numpy()
+    assert np.array_equal(got, want)
+    if pad:
+        assert torch.all(oview[:, orl:] == -5.0)       # nothing written between the rows
+    assert float(oflat[0]) == -5.0 or shift == 0        # ... nor before a shifted base
+    for h in ins + [ho]:
+        _lib.check(_lib.lib().gaast_hip_mv_free(h))
