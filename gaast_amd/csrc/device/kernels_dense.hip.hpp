@@ -10,22 +10,14 @@
 #ifndef GAAST_MFMA32_LEAN      /* k_gp_mfma32: B addresses as (lane constant) ^ (step constant), block sign in three instructions */
 #define GAAST_MFMA32_LEAN 1
 #endif
-#ifndef GAAST_MFMA16_BSIGN_MUL
-#define GAAST_MFMA16_BSIGN_MUL 0
-#endif
 #ifndef GAAST_DENSE_NO_CANON
 #define GAAST_DENSE_NO_CANON 0
-#endif
-// k_gp_mfma16: keep a NEGATED copy of the B image in LDS and pick the image by the block sign (one address term per step
-// instead of 16 sign flips)
-#ifndef GAAST_MFMA16_NEGB
-#define GAAST_MFMA16_NEGB 0
 #endif
 #ifndef GAAST_MFMA16_SETPRIO
 #define GAAST_MFMA16_SETPRIO 1
 #endif
-#ifndef GAAST_MFMA16_UNROLL
-#define GAAST_MFMA16_UNROLL 1
+#ifndef GAAST_MFMA16_PRIO_RAMP
+#define GAAST_MFMA16_PRIO_RAMP 0
 #endif
 #define GAAST_STR2(x) #x
 #define GAAST_STR(x) GAAST_STR2(x)
@@ -76,6 +68,7 @@ struct DenseArgs {
     uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
     uint32_t neg_lo;            // lo basis vectors that square to -1
     int beta;
+    int out_rows;               // k_gp_mfma16: every blade is produced into 16-byte aligned rows of 2^n words, beta = 0
     int64_t batch;
 };
 
@@ -645,34 +638,75 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // per instruction.  With lo = 4 bits the contribution of block a_hi to the 16 result columns c_hi of a tile is
 // a 16 x 16 x 16 GEMM per ITEM; the four blocks of the instruction are four items, so one wave owns all
 // 16 x 16 results (n = 8; half of them at n = 9) of four items:
-//   lane 16 b + i:  A operand = +-A_b[a_hi][i ^ k]   (gather, lane-constant offset and sign per k)
-//                   B operand = +-B_b[a_hi ^ c_hi(i)][k]   (the lane's block, 4 ds_read_b128 per step)
-//   16 instructions (k = 0..15) per step.  Same sums as k_gp_mfma32 / k_gp_dense: a k-ordered fmaf chain.
-// Operand images: A in plain blade order, B in the vector kernel's quad-rotated order; items are 2^(n+1) + 16
-// words apart so that the four items of a wave sit on different banks.
+//   lane 16 b + i:  A operand = +-A_b[a_hi][i ^ k]          (lane-constant position and sign per term k)
+//                   B operand = +-B_b[a_hi ^ c_hi(i)][k]    (the lane's block; sign per lane and step)
+//   16 instructions (one per k) per step.  Same sums as k_gp_mfma32 / k_gp_dense: a k-ordered fmaf chain.
+//
+// On this chip every vector instruction of a resident wave costs the SIMD ~4.8 cycles the f32 matrix pipe does not get
+// (tools/microbench/mfma16_loop2.hip), LDS reads do not.  So NO sign is applied with vector instructions: each item keeps
+// FOUR images in LDS, +A, -A, +B, -B, and every sign is an ADDRESS:
+//   * A operand of term k: one ds_read_b32 at (lane constant of k) + 64 a_hi -- the constant points into +A or -A by the
+//     lane-constant sign of (i, k) (reordering sign of the lo bits, lo vectors that square to -1);
+//   * B operand: the lane's block from +B or -B by the block sign of (a_hi, c_hi): one address bit per step.
+//   The remaining factor (-1)^(|a_hi| |k|) is split with |a_hi| = |b_hi| + |c_hi| (mod 2): the b_hi part is folded
+//   into the B images while staging (host map), the c_hi part is a lane constant of the odd-|k| words: the words of a
+//   block are stored even-|k| first (two 16-byte quads), odd-|k| last, and lanes with odd |c_hi| read the odd quads
+//   from the image of the other sign.
+// Per step of 16 MFMAs: 16 ds_read_b32 + 4 ds_read_b128 and six vector instructions (the B addresses).
+// Operand images: A in plain blade order; B blocks of 16 words in the order above, the four quads of block x rotated by
+// (x >> 2) & 3 (16 lanes reading 16 blocks: 16 different bank quads); items are 4 * 2^n + 16 words apart, the 16 spare
+// words stay zero (the B "block" of a vanishing contribution, degenerate metrics).
 // ------------------------------------------------------------------------------------------
 // One workgroup = ONE group of four items (n = 8: a single wave, n = 9: two waves), persistent: no synchronisation
 // between the groups a CU works on, their staging / product / store phases drift apart and fill each other's stalls.
 // FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): the rows of the next group
 // are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging of
 // stage_operands (partial grade sets, strided / unaligned rows).
+// Workgroup barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and
+// loads (vmcnt(0)): between the groups of a persistent workgroup that is the round trip of the result rows to HBM.
+// A single-wave workgroup needs no barrier at all: the LDS executes a wave's instructions in order.
+template <int THREADS>
+__device__ __forceinline__ void lds_barrier() {
+    if (THREADS <= 64) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+// term t of a step multiplies the words k = mfma16_k(t): even |k| first
+__device__ __forceinline__ constexpr int mfma16_k(int t) {
+    constexpr int order[16] = {0, 3, 5, 6, 9, 10, 12, 15, 1, 2, 4, 7, 8, 11, 13, 14};
+    return order[t];
+}
+
 template <bool DEGENERATE, int NDIM, bool FAST>
-__global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gp_mfma16(DenseArgs<float> p) {
+__global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_gp_mfma16(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
+    lds_u8* lds = (lds_u8*)smem_raw;
     constexpr int n = NDIM;                       // 8 or 9
     constexpr int N = 1 << n;
     constexpr int H = 1 << (n - 4);               // number of 16-blocks
     constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
     constexpr int IPB = 4;                        // items per workgroup pass: the four blocks of the instruction
-    constexpr int item_stride = (GAAST_MFMA16_NEGB ? 3 : 2) * N + 16;   // A image, B image[, -B image]
+    constexpr int item_stride = 4 * N + 16;       // words: +A, -A, +B, -B images, 16 zero words
+    constexpr uint32_t NEG = uint32_t(N) * 4u;    // bytes from an image to its negated copy (one address bit)
+    constexpr uint32_t ITEM_BYTES = uint32_t(item_stride) * 4u;
     constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row == THREADS: thread t moves piece t of every row
     static_assert(COUNT4 == THREADS, "one 16-byte piece of each row per thread");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
 
-    // byte address of each of the thread's 4 + 4 components inside item 0's images (item k is a compile-time distance
-    // away), and their negate bits
+    // the 16 spare words of every item: zero for the whole launch
+    if (tid < 16 * IPB) smem[(tid >> 4) * item_stride + 4 * N + (tid & 15)] = 0.f;
+
+    // byte address of each of the thread's 4 + 4 components inside item 0's +A / +B images (item k is a compile-time
+    // distance away), and their negate bits
     uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
     if (FAST) {
         const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[tid], mr = reinterpret_cast<const uint4*>(p.right_map)[tid];
@@ -680,9 +714,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             wa[c] = ((mls[c] >> 16) & 0x7fffu) << 2;
-            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(N)) << 2;
-            sa[c] = mls[c] & 0x80000000u;     // a folded Negation / Reverse / GradeInvolution, or the basis permutation's sign
-            sb[c] = mrs[c] & 0x80000000u;
+            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(2 * N)) << 2;
+            sa[c] = mls[c] & 0x80000000u;     // a folded Negation / Reverse / GradeInvolution, the basis permutation's sign,
+            sb[c] = mrs[c] & 0x80000000u;     // (B) the (-1)^(|b_hi| |k|) of the image
         }
     }
     float4 pf_l[IPB], pf_r[IPB];
@@ -697,7 +731,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             }
         }
     };
-    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon, bool with_negative) {
+    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon) {
         const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -705,30 +739,28 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #if !GAAST_DENSE_NO_CANON
             if (canon) y = 0.f + y;           // the reference's zero-init + add_grades_from copy: 0.0 + x
 #endif
-            y = __uint_as_float(__float_as_uint(y) ^ sg[c]);
-            *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * item_stride * 4)) = y;
-            if (with_negative) *reinterpret_cast<float*>(smem_raw + w[c] + uint32_t(k * item_stride * 4 + N * 4)) = -y;
+            const uint32_t yb = __float_as_uint(y) ^ sg[c];
+            *(__attribute__((address_space(3))) uint32_t*)(lds + w[c] + uint32_t(k) * ITEM_BYTES) = yb;
+            *(__attribute__((address_space(3))) uint32_t*)(lds + w[c] + uint32_t(k) * ITEM_BYTES + NEG) = yb ^ 0x80000000u;
         }
     };
     if (FAST && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
 
     const int tile = tid >> 6, lane = tid & 63;   // wave <-> 16 result columns
     const int blk = lane >> 4, i = lane & 15;     // lane's item of the group (operand side), row / column inside the tile
-    const float* As = smem + blk * item_stride;
-    const float* Bs = As + N;
     const int c_hi = (tile << 4) | i;
 
-    // The A operand of lane i for term k is +-A[a_hi][i ^ k]: the lane reads ITS OWN word A[a_hi][i] once per step and
-    // the 16 lanes of the item exchange them through DPP (no LDS gather, no address arithmetic): lane i <- lane i ^ k.
-    // amask[k]: sign of that operand, a lane constant (reordering sign of the lo bits, lo vectors that square to -1).
-    uint32_t amask[16];
+    // A operand of term t (k = mfma16_k(t)): +-A[a_hi][i ^ k], sign a lane constant (reordering sign of the lo bits, lo
+    // vectors that square to -1): byte address inside the item's +A / -A pair, without the step's 64 a_hi
+    uint32_t ak[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int t = 0; t < 16; ++t) {
+        const int k = mfma16_k(t);
         const int a_lo = i ^ k;
         int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-        amask[k] = uint32_t(par) << 31;
+        ak[t] = uint32_t(blk) * ITEM_BYTES + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
     }
     // block sign of every step, one bit per a_hi: (-1)^(u(a_hi) + parity(c_hi & M(a_hi))), and (DEGENERATE) the
     // steps whose contribution to this lane's column vanishes
@@ -744,13 +776,17 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
         sign_bits |= ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << a_hi;
         if (DEGENERATE) zero_bits |= ((uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? 1u : 0u) << a_hi;
     }
-    const uint32_t* As_own = reinterpret_cast<const uint32_t*>(As) + i;
-    const unsigned char* Bs_b = reinterpret_cast<const unsigned char*>(Bs);
-    // B block x = a_hi ^ c_hi, its four 16-byte quads rotated by (x >> 2) & 3 (dense_lds_pos): the byte offset of
-    // logical quad q is (lane constant) ^ (step constant)
+    // B block x = a_hi ^ c_hi, its four 16-byte quads rotated by (x >> 2) & 3 (host: the map's positions): the byte
+    // offset of logical quad q inside the +B / -B pair is (lane constant) ^ (step constant); quads 2, 3 hold the odd-|k|
+    // words, which lanes with odd |c_hi| take from the other image
+    const uint32_t b_base = uint32_t(blk) * ITEM_BYTES + 2u * NEG;
+    const uint32_t zero_block = uint32_t(blk) * ITEM_BYTES + 4u * NEG;
     uint32_t bq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[q] = (uint32_t(c_hi) << 6) | (uint32_t((q ^ (c_hi >> 2)) & 3) << 4);
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = (uint32_t(c_hi) << 6) | (uint32_t((q ^ (c_hi >> 2)) & 3) << 4);
+        if (q >= 2 && (__builtin_popcount(uint32_t(c_hi)) & 1)) bq[q] ^= NEG;
+    }
     // where this lane's results go: register 4 b + r = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + (lane & 15):
     // byte offset in the result row, sign of the basis permutation, "not produced"
     const int rg = lane >> 4;
@@ -772,120 +808,103 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
 #pragma unroll
             for (int k = 0; k < IPB; ++k) {
                 if (k < nitems) {
-                    scatter4(k, pf_l[k], wa, sa, p.canon_left, false);
-                    scatter4(k, pf_r[k], wb, sb, p.canon_right, GAAST_MFMA16_NEGB != 0);
+                    scatter4(k, pf_l[k], wa, sa, p.canon_left);
+                    scatter4(k, pf_r[k], wb, sb, p.canon_right);
                 }
             }
         } else {
             if (!p.left_full || !p.right_full) {
                 for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
-                __syncthreads();
+                lds_barrier<THREADS>();
             }
             stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
                                            p.canon_left, smem, item_stride, nitems, tid);
             stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                           p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
-#if GAAST_MFMA16_NEGB
-            __syncthreads();
-            for (int e = tid; e < nitems * N; e += THREADS) {
-                const int sit = e / N, j = e - sit * N;
-                smem[sit * item_stride + 2 * N + j] = -smem[sit * item_stride + N + j];
+                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
+            lds_barrier<THREADS>();
+            for (int e = tid; e < nitems * 2 * N; e += THREADS) {   // the negated images
+                const int sit = e / (2 * N), j = e - sit * (2 * N);
+                const int src = sit * item_stride + (j < N ? j : j + N);
+                smem[src + N] = -smem[src];
             }
-#endif
         }
-        __syncthreads();   // one wave at n = 8: no wait
+        lds_barrier<THREADS>();
         if (FAST && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
 
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-        auto one_step = [&](int a_hi) {
-            // block sign and (DEGENERATE) block mask of this lane's B block
-            const uint32_t sbit = ((sign_bits >> a_hi) & 1u) << 31;
-            uint32_t keep = 0xffffffffu;
-            if (DEGENERATE) keep = ((zero_bits >> a_hi) & 1u) ? 0u : 0xffffffffu;
-#if GAAST_MFMA16_BSIGN_MUL
-            float sg1 = __uint_as_float(0x3f800000u | sbit);
-            if (DEGENERATE) sg1 = keep ? sg1 : 0.f;
-            const float2v sgn2 = float2v{sg1, sg1};
-#endif
-            const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
-            uint32_t bw[16];
-#if GAAST_MFMA16_NEGB
-            const unsigned char* Bsel = Bs_b + (sbit ? uint32_t(N * 4) : 0u);     // the lane's B block from the image of its sign
-#else
-            const unsigned char* Bsel = Bs_b;
-#endif
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = *reinterpret_cast<const uint4*>(Bsel + (bq[q] ^ sx));
-                bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
-            }
-            const uint32_t w0 = As_own[a_hi << 4];
-            const uint32_t t7 = dpp_row<DPP_ROW_HALF_MIRROR>(w0), t15 = dpp_row<DPP_ROW_MIRROR>(w0);
-            const uint32_t w4 = dpp_row<DPP_QX3>(t7), w8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15), w12 = dpp_row<DPP_QX3>(t15);
-            auto term = [&](auto ktag, uint32_t base) {
-                constexpr int k = decltype(ktag)::value;
-                const float a = __uint_as_float(dpp_quad_xor<(k & 3)>(base) ^ amask[k]);
-#if GAAST_MFMA16_BSIGN_MUL
-                const float2v bp2 = float2v{__uint_as_float(bw[k & ~1]), __uint_as_float(bw[k | 1])} * sgn2;
-                const float bf = (k & 1) ? bp2.y : bp2.x;
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, bf, acc, 0, 0, 0);
-#elif GAAST_MFMA16_NEGB
-                uint32_t b = bw[k];
-                if (DEGENERATE) b &= keep;
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, __uint_as_float(b), acc, 0, 0, 0);
-#else
-                uint32_t b = bw[k] ^ sbit;
-                if (DEGENERATE) b &= keep;
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, __uint_as_float(b), acc, 0, 0, 0);
-#endif
-            };
-            term(std::integral_constant<int, 0>{}, w0);   term(std::integral_constant<int, 1>{}, w0);
-            term(std::integral_constant<int, 2>{}, w0);   term(std::integral_constant<int, 3>{}, w0);
-            term(std::integral_constant<int, 4>{}, w4);   term(std::integral_constant<int, 5>{}, w4);
-            term(std::integral_constant<int, 6>{}, w4);   term(std::integral_constant<int, 7>{}, w4);
-            term(std::integral_constant<int, 8>{}, w8);   term(std::integral_constant<int, 9>{}, w8);
-            term(std::integral_constant<int, 10>{}, w8);  term(std::integral_constant<int, 11>{}, w8);
-            term(std::integral_constant<int, 12>{}, w12); term(std::integral_constant<int, 13>{}, w12);
-            term(std::integral_constant<int, 14>{}, w12); term(std::integral_constant<int, 15>{}, w12);
-        };
-        // (unrolling these loops makes the block index a constant but costs all the registers)
-        constexpr int half = H >> 1;
+        // n = 8: the 64 B addresses of a group (16 steps x 4 quads) are lane constants the compiler keeps in registers
+        // (no vector instruction in the loop); n = 9 would need 128: recomputed per group, 6 instructions per step
+        uint32_t sign_now = sign_bits;
+        if (NDIM > 8) asm volatile("" : "+v"(sign_now));
 #if GAAST_MFMA16_SETPRIO
         __builtin_amdgcn_s_setprio(2);   // waves in their product phase go first
 #endif
-_Pragma(GAAST_STR(unroll GAAST_MFMA16_UNROLL))
-        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
 #pragma unroll
-        for (int k = 0; k < 16; ++k)  // (-1)^(|a_hi| |k|) for odd |a_hi|
-            amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
-_Pragma(GAAST_STR(unroll GAAST_MFMA16_UNROLL))
-        for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | ((__builtin_popcount(uint32_t(t2)) & 1) ^ 1));
+        for (int a_hi = 0; a_hi < H; ++a_hi) {
+            // the lane's B block, from the image of its block sign
+            const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
+            const uint32_t sxs = sx | (((sign_now >> a_hi) & 1u) ? NEG : 0u);
+            uint32_t bw[16], aw[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)  // back to the even-|a_hi| pattern for the next group
-            amask[k] ^= uint32_t(__builtin_popcount(uint32_t(k)) & 1) << 31;
+            for (int q = 0; q < 4; ++q) {
+                uint32_t addr = b_base + (bq[q] ^ sxs);
+                if (DEGENERATE) addr = ((zero_bits >> a_hi) & 1u) ? zero_block : addr;
+                const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
+                bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(a_hi << 6));
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
+            asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+#if GAAST_MFMA16_SETPRIO && GAAST_MFMA16_PRIO_RAMP
+            if (a_hi == H / 2 - 1) __builtin_amdgcn_s_setprio(3);   // the wave that is ahead stays ahead: co-resident waves drift out of phase
+#endif
+        }
 #if GAAST_MFMA16_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
 
-        // ---- results -> graded rows: (uniform) row base + the lane's byte offsets ----
+        if (p.out_rows) {
+            // ---- results -> the items' (dead) +A images in result-row order, then whole rows in 16-byte pieces ----
+            lds_barrier<THREADS>();   // every wave is done with the images
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b < nitems) {
-                unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + (item0 + b) * p.out_stride);
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ook[r]) {
-                        float* q = reinterpret_cast<float*>(orow + ooff[r]);
-                        const float v = __uint_as_float(__float_as_uint(acc[4 * b + r]) ^ osg[r]);
-                        *q = p.beta ? *q + v : v;
+                for (int r = 0; r < 4; ++r)
+                    *(__attribute__((address_space(3))) uint32_t*)(lds + uint32_t(b) * ITEM_BYTES + ooff[r]) =
+                        __float_as_uint(acc[4 * b + r]) ^ osg[r];
+            lds_barrier<THREADS>();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nitems) {
+                    const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + uint32_t(b) * ITEM_BYTES + uint32_t(tid) * 16u);
+                    reinterpret_cast<uint4v*>(p.out + (item0 + b) * p.out_stride)[tid] = v;
+                }
+            }
+        } else {
+            // ---- results -> graded rows: (uniform) row base + the lane's byte offsets ----
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < nitems) {
+                    unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + (item0 + b) * p.out_stride);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ook[r]) {
+                            float* q = reinterpret_cast<float*>(orow + ooff[r]);
+                            const float v = __uint_as_float(__float_as_uint(acc[4 * b + r]) ^ osg[r]);
+                            *q = p.beta ? *q + v : v;
+                        }
                     }
                 }
             }
         }
-        __syncthreads();   // the LDS images are rewritten by the next group
+        lds_barrier<THREADS>();   // the LDS images are rewritten by the next group
     }
 }
 

@@ -587,6 +587,12 @@ struct Lowering {
                 const uint32_t x = m >> 4, lo = m & 15;
                 return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
             };
+            // k_gp_mfma16's B image: the words of block x stored even-|k| first (term order mfma16_k), quads rotated as above
+            auto mfma16_b_pos = [](uint32_t m) {
+                static const int word_of_k[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
+                const uint32_t x = m >> 4, w = uint32_t(word_of_k[m & 15]);
+                return (x << 4) | ((((w >> 2) ^ (x >> 2)) & 3) << 2) | (w & 3);
+            };
             auto mfma_b_pos = [](uint32_t m) {
                 const uint32_t x = m >> 5, k = m & 31;
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
@@ -601,9 +607,12 @@ struct Lowering {
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
                         const uint32_t orig = bt.blade_of[size_t(k)][i];
                         const uint32_t blade = new_blade[orig];
-                        const uint32_t sgn = (uint32_t((flip >> k) & 1ULL) ^ blade_sign[orig]) ? 0x80000000u : 0u;
+                        uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ blade_sign[orig];
+                        // k_gp_mfma16: the b_hi part of (-1)^(|a_hi| |b_lo|), |a_hi| = |b_hi| + |c_hi| (mod 2), lives in the B image
+                        if (s.use_mfma16 && right) neg ^= uint32_t(__builtin_popcount(blade >> 4) & __builtin_popcount(blade & 15u) & 1);
+                        const uint32_t sgn = neg ? 0x80000000u : 0u;
                         const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
-                                             : s.use_mfma16 ? (right ? vec_pos(blade) : blade) : vec_pos(blade);
+                                             : s.use_mfma16 ? (right ? mfma16_b_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();
                         map.push_back(off | (pos << 16) | sgn);
@@ -621,6 +630,9 @@ struct Lowering {
                 if ((omin >> g) & 1ULL)
                     s.i32_a[new_blade[m]] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (blade_sign[m] << 30));
             }
+            // every blade produced into a row that holds nothing else: whole rows can be written in 16-byte pieces
+            s.out_full = lr.row_len == (int64_t(1) << n);
+            for (uint32_t m = 0; m < (1u << n); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
             const int lo_bits = s.use_mfma ? 5 : 4;
             for (int j = 0; j < n; ++j) {
                 const double g = d.metric_diag[perm[size_t(j)]];

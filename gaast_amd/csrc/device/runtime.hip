@@ -248,7 +248,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             if constexpr (!is_f64) {
                 s.threads = 64 << (n - 8);                     // one wave per 16 result columns of a group of four items
                 s.items_per_block = 4;
-                s.lds = size_t(4) * size_t((GAAST_MFMA16_NEGB ? 3 : 2) * (size_t(1) << n) + 16) * sizeof(float);   // A, B[, -B] images of four items
+                s.lds = size_t(4) * size_t(4 * (size_t(1) << n) + 16) * sizeof(float);   // +A, -A, +B, -B images of four items
                 // [0]: general staging; [1]: register prefetch, when both operands are full rows that turn out
                 // contiguous and 16-byte aligned at launch
                 using KernD = void (*)(DenseArgs<float>);
@@ -440,6 +440,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.zero_hi = s.zero_hi;
         p.neg_lo = s.neg_lo;
         p.beta = s.beta;
+        p.out_rows = s.use_mfma16 && s.out_full && !s.beta && aligned(res.ptr, res.stride);
         p.batch = batch;
         using KernD = void (*)(DenseArgs<T>);
         const int64_t groups = (batch + s.items_per_block - 1) / s.items_per_block;
