@@ -633,6 +633,165 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
 }
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and
+// loads (vmcnt(0)): between the groups of a persistent workgroup that is the round trip of the result rows to HBM.
+// A single-wave workgroup needs no barrier at all: the LDS executes a wave's instructions in order.
+template <int THREADS>
+__device__ __forceinline__ void lds_barrier() {
+    if (THREADS <= 64) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+// term t of a step multiplies the words k = mfma16_k(t): even |k| first
+__device__ __forceinline__ constexpr int mfma16_k(int t) {
+    constexpr int order[16] = {0, 3, 5, 6, 9, 10, 12, 15, 1, 2, 4, 7, 8, 11, 13, 14};
+    return order[t];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gp_mfma32 in image-pair form (n = 10 ... 13): as k_gp_mfma16 below, NO sign is applied with vector instructions
+// (each costs the SIMD ~4.8 cycles of matrix-pipe time, tools/microbench/mfma16_loop2.hip).  Every item keeps +A, -A,
+// +B, -B images in LDS (4 x 2^n words) and every sign is an address:
+//   * A operand of term t (s2 = mfma16_k(t), k = 2 s2 + h): one ds_read_b32 at (lane constant of t) + 128 a_hi; the
+//     constant points into +A or -A by the lane-constant sign of (i, k);
+//   * B operand: the lane's 16 words of block a_hi ^ c_hi from +B or -B by the block sign (one address bit per step);
+//   * (-1)^(|a_hi| |k|), |a_hi| = |b_hi| + |c_hi| (mod 2): the b_hi part is folded into the B images (host map); for
+//     the c_hi part the lane's 16 words are stored even-|s2| first, so that each 16-byte quad holds words of one |k|
+//     parity, and lanes with odd |c_hi| read the odd-|k| quads from the image of the other sign.
+// Steps run in chunks of eight (immediate offsets for the A reads, the 16 A addresses move once per chunk): per step of
+// 16 MFMAs (1,024 matrix-pipe cycles) 16 ds_read_b32 + 4 ds_read_b128 and ~10 vector instructions.
+// n = 14 does not fit (4 x 64 KiB) and stays on k_gp_mfma32.
+// ------------------------------------------------------------------------------------------
+template <bool DEGENERATE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_mfma32p(DenseArgs<float> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    lds_u8* lds = (lds_u8*)smem_raw;
+    const int n = p.n;
+    const int N = 1 << n;
+    const int hbits = n - 5;
+    const int H = 1 << hbits;                     // number of 32-blocks
+    const int WPI = H >> 5;                       // waves per item (32 result columns each)
+    const int IPB = (THREADS >> 6) / WPI;         // items per block (>= 1)
+    const int item_stride = 4 * N;                // words: +A, -A, +B, -B
+    const uint32_t NEG = uint32_t(N) << 2;        // bytes from an image to its negated copy (one address bit)
+    const int tid = threadIdx.x;
+    const int64_t item0 = int64_t(blockIdx.x) * IPB;
+    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+
+    // ---- stage both operands in bitmask order (+A, +B), then their negated copies ----
+    if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
+    if (!p.left_full || !p.right_full) {
+        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
+        __syncthreads();
+    }
+    stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                   p.canon_left, smem, item_stride, nitems, tid);
+    stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                   p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
+    __syncthreads();
+    {
+        const int quads_per_item = N >> 1;        // 16-byte pieces of +A and +B together
+        for (int e = tid; e < nitems * quads_per_item; e += THREADS) {
+            const int sit = e / quads_per_item, j = e - sit * quads_per_item;
+            const int src = sit * item_stride + (j << 2) + ((j << 2) < N ? 0 : N);
+            const float4v v = *reinterpret_cast<const float4v*>(smem + src);
+            *reinterpret_cast<float4v*>(smem + src + N) = -v;
+        }
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int it = wave / WPI, tile = wave - it * WPI;
+    if (it < nitems) {
+        const int i = lane & 31, h = lane >> 5;
+        const int c_hi = (tile << 5) | i;
+        const uint32_t item_base = uint32_t(it) * uint32_t(item_stride) * 4u;
+
+        // A operand of term t: s2 = mfma16_k(t), k = 2 s2 + h: +-A[a_hi][i ^ k], sign a lane constant: byte address
+        // inside the item's +A / -A pair, without the step's 128 a_hi
+        uint32_t ak[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 2 * mfma16_k(t) + h;
+            const int a_lo = i ^ k;
+            int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
+            for (int pp = 1; pp < 5; ++pp)
+                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+            ak[t] = item_base + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
+        }
+        // B side: byte offset of the lane's quad q inside the +B / -B pair = (lane constant) ^ (step constant); quads
+        // 0, 1 hold the even-|s2| words (|k| parity h), quads 2, 3 the odd ones: lanes with odd |c_hi| take the odd-|k|
+        // quads from the other image.  c_hi with a spare bit set: the uniform part u of the block sign rides in the popcount
+        const uint32_t b_base = item_base + 2u * NEG;
+        const uint32_t zero_block = uint32_t(IPB) * uint32_t(item_stride) * 4u;
+        uint32_t bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[q] = (uint32_t(c_hi) << 7) | (uint32_t((((h << 2) | q) ^ (c_hi >> 1)) & 7) << 4);
+            if ((__builtin_popcount(uint32_t(c_hi)) & 1) && (((q >> 1) ^ h) & 1)) bq[q] ^= NEG;
+        }
+        const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
+        const uint32_t neg_shift = uint32_t(n + 2);
+
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        for (int a0 = 0; a0 < H; a0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int a_hi = a0 + j;
+                // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
+                uint32_t sp = uint32_t(a_hi) >> 1;
+                sp ^= sp >> 1;
+                sp ^= sp >> 2;
+                sp ^= sp >> 4;
+                sp ^= sp >> 8;
+                const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+                const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                    __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+                const uint32_t sbit = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) & 1u;
+                const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+                const uint32_t sxs = (sbit << neg_shift) | sx;
+                uint32_t bw[16], aw[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t addr = b_base + (bq[q] ^ sxs);
+                    if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
+                    const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
+                    bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
+                asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ak[t] += 8u << 7;
+        }
+
+        // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
+        float* orow = p.out + (item0 + it) * p.out_stride;
+        const int32_t* om = p.out_map + (c_hi << 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
+            store_result<float>(orow, om[c_lo], acc[r], p.beta);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Matrix-core form for n = 8, 9 (f32): v_mfma_f32_16x16x1_4b_f32, four independent 16 x 16 outer products
 // per instruction.  With lo = 4 bits the contribution of block a_hi to the 16 result columns c_hi of a tile is
@@ -662,28 +821,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 // FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): the rows of the next group
 // are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging of
 // stage_operands (partial grade sets, strided / unaligned rows).
-// Workgroup barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and
-// loads (vmcnt(0)): between the groups of a persistent workgroup that is the round trip of the result rows to HBM.
-// A single-wave workgroup needs no barrier at all: the LDS executes a wave's instructions in order.
-template <int THREADS>
-__device__ __forceinline__ void lds_barrier() {
-    if (THREADS <= 64) {
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-}
-
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
-
-// term t of a step multiplies the words k = mfma16_k(t): even |k| first
-__device__ __forceinline__ constexpr int mfma16_k(int t) {
-    constexpr int order[16] = {0, 3, 5, 6, 9, 10, 12, 15, 1, 2, 4, 7, 8, 11, 13, 14};
-    return order[t];
-}
-
 template <bool DEGENERATE, int NDIM, bool FAST>
 __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_gp_mfma16(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -562,6 +562,7 @@ struct Lowering {
             const int n = d.vec_space_dim;
             s.use_mfma = dense_kind == 3;
             s.use_mfma16 = dense_kind == 2;
+            s.mfma32_pairs = dense_kind == 3 && n <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
             // blade S of the program's basis <-> blade S' of the permuted basis, e_S = sign(S) e'_S' (the parity of the
             // inversions of the new positions of S's vectors taken in ascending original order)
             std::vector<int> inv(size_t(n), 0);
@@ -593,6 +594,13 @@ struct Lowering {
                 const uint32_t x = m >> 4, w = uint32_t(word_of_k[m & 15]);
                 return (x << 4) | ((((w >> 2) ^ (x >> 2)) & 3) << 2) | (w & 3);
             };
+            // k_gp_mfma32p's B image: the lane's 16 words (k of one parity) even-|k >> 1| first, quads rotated as in mfma_b_pos
+            auto mfma32p_b_pos = [](uint32_t m) {
+                static const int word_of_s[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
+                const uint32_t x = m >> 5, k = m & 31, w = uint32_t(word_of_s[k >> 1]);
+                const uint32_t lq = ((k & 1) << 2) | (w >> 2);
+                return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | (w & 3);
+            };
             auto mfma_b_pos = [](uint32_t m) {
                 const uint32_t x = m >> 5, k = m & 31;
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
@@ -610,8 +618,10 @@ struct Lowering {
                         uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ blade_sign[orig];
                         // k_gp_mfma16: the b_hi part of (-1)^(|a_hi| |b_lo|), |a_hi| = |b_hi| + |c_hi| (mod 2), lives in the B image
                         if (s.use_mfma16 && right) neg ^= uint32_t(__builtin_popcount(blade >> 4) & __builtin_popcount(blade & 15u) & 1);
+                        if (s.mfma32_pairs && right) neg ^= uint32_t(__builtin_popcount(blade >> 5) & __builtin_popcount(blade & 31u) & 1);
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
-                        const uint32_t pos = s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
+                        const uint32_t pos = s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
+                                             : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
                                              : s.use_mfma16 ? (right ? mfma16_b_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();

@@ -235,6 +235,14 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 const int wpi = 1 << (n - 10);                 // waves per item
                 s.threads = wpi > 4 ? wpi * 64 : 256;
                 s.items_per_block = (s.threads / 64) / wpi;
+                if (s.mfma32_pairs) {
+                    s.lds = (size_t(s.items_per_block) * size_t(4 << n) + 16) * sizeof(float);
+                    if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
+                    auto kernp = s.threads == 256 ? (s.degenerate ? &k_gp_mfma32p<true, 256> : &k_gp_mfma32p<false, 256>)
+                                                  : (s.degenerate ? &k_gp_mfma32p<true, 512> : &k_gp_mfma32p<false, 512>);
+                    s.kern[0] = reinterpret_cast<const void*>(kernp);
+                    return allow_lds(s.kern[0], s.lds);
+                }
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
                 auto kern = s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
