@@ -669,126 +669,194 @@ __device__ __forceinline__ constexpr int mfma16_k(int t) {
 // 16 MFMAs (1,024 matrix-pipe cycles) 16 ds_read_b32 + 4 ds_read_b128 and ~10 vector instructions.
 // n = 14 does not fit (4 x 64 KiB) and stays on k_gp_mfma32.
 // ------------------------------------------------------------------------------------------
-template <bool DEGENERATE, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_gp_mfma32p(DenseArgs<float> p) {
+// Persistent workgroups: a workgroup walks the groups of IPB items blockIdx.x, blockIdx.x + gridDim.x, ...; when both
+// operands hold every blade in consecutive 16-byte aligned rows (p.left_contig / left_full ...: the host checks), the
+// rows of the NEXT group are fetched into registers (8 x 16 B per thread at every n) while the matrix cores work on the
+// current one; barriers between the phases wait for LDS traffic only (lds_barrier).
+template <bool DEGENERATE, int NDIM>
+__global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
-    const int n = p.n;
-    const int N = 1 << n;
-    const int hbits = n - 5;
-    const int H = 1 << hbits;                     // number of 32-blocks
-    const int WPI = H >> 5;                       // waves per item (32 result columns each)
-    const int IPB = (THREADS >> 6) / WPI;         // items per block (>= 1)
-    const int item_stride = 4 * N;                // words: +A, -A, +B, -B
-    const uint32_t NEG = uint32_t(N) << 2;        // bytes from an image to its negated copy (one address bit)
+    constexpr int n = NDIM;
+    constexpr int THREADS = NDIM == 13 ? 512 : 256;
+    constexpr int N = 1 << n;
+    constexpr int H = 1 << (n - 5);               // number of 32-blocks
+    constexpr int WPI = H >> 5;                   // waves per item (32 result columns each)
+    constexpr int IPB = (THREADS >> 6) / WPI;     // items per group (>= 1)
+    constexpr int item_stride = 4 * N;            // words: +A, -A, +B, -B
+    constexpr uint32_t NEG = uint32_t(N) << 2;    // bytes from an image to its negated copy (one address bit)
+    constexpr int PR = N / 4;                     // 16-byte pieces of a row
+    constexpr int MPR = PR / THREADS;             // pieces of one row per thread (1, 2, 4)
+    constexpr int ROWS = 2 * IPB;                 // rows of a group: the items' left rows, then their right rows
+    static_assert(MPR * ROWS == 8, "eight 16-byte pieces per thread and group");
     const int tid = threadIdx.x;
-    const int64_t item0 = int64_t(blockIdx.x) * IPB;
-    const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+    const int64_t num_groups = (p.batch + IPB - 1) / IPB;
+    const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full;
 
-    // ---- stage both operands in bitmask order (+A, +B), then their negated copies ----
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
-    if (!p.left_full || !p.right_full) {
-        for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = 0.f;
-        __syncthreads();
-    }
-    stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                   p.canon_left, smem, item_stride, nitems, tid);
-    stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                   p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
-    __syncthreads();
-    {
-        const int quads_per_item = N >> 1;        // 16-byte pieces of +A and +B together
-        for (int e = tid; e < nitems * quads_per_item; e += THREADS) {
-            const int sit = e / quads_per_item, j = e - sit * quads_per_item;
-            const int src = sit * item_stride + (j << 2) + ((j << 2) < N ? 0 : N);
-            const float4v v = *reinterpret_cast<const float4v*>(smem + src);
-            *reinterpret_cast<float4v*>(smem + src + N) = -v;
+
+    // FAST: thread t moves pieces t + m THREADS (m < MPR) of every row; their map words (position, sign) stay in registers
+    uint32_t mw[2][MPR * 4];
+    float4 pf[8];
+    auto fetch = [&](int64_t g) {
+        const int64_t it0 = g * IPB;
+        const int cnt = int(p.batch - it0 < IPB ? p.batch - it0 : IPB);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int k = r % IPB;                // item of the group
+            if (k < cnt) {
+                const float* row = r < IPB ? p.left + (it0 + k) * p.left_stride : p.right + (it0 + k) * p.right_stride;
+#pragma unroll
+                for (int m = 0; m < MPR; ++m) pf[r * MPR + m] = reinterpret_cast<const float4*>(row)[tid + m * THREADS];
+            }
         }
+    };
+    if (fast) {
+#pragma unroll
+        for (int m = 0; m < MPR; ++m) {
+            const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[tid + m * THREADS];
+            const uint4 mr = reinterpret_cast<const uint4*>(p.right_map)[tid + m * THREADS];
+            mw[0][4 * m + 0] = ml.x; mw[0][4 * m + 1] = ml.y; mw[0][4 * m + 2] = ml.z; mw[0][4 * m + 3] = ml.w;
+            mw[1][4 * m + 0] = mr.x; mw[1][4 * m + 1] = mr.y; mw[1][4 * m + 2] = mr.z; mw[1][4 * m + 3] = mr.w;
+        }
+        if (int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
     }
-    __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
     const int it = wave / WPI, tile = wave - it * WPI;
-    if (it < nitems) {
-        const int i = lane & 31, h = lane >> 5;
-        const int c_hi = (tile << 5) | i;
-        const uint32_t item_base = uint32_t(it) * uint32_t(item_stride) * 4u;
+    const int i = lane & 31, h = lane >> 5;
+    const int c_hi = (tile << 5) | i;
+    const uint32_t item_base = uint32_t(it) * uint32_t(item_stride) * 4u;
 
-        // A operand of term t: s2 = mfma16_k(t), k = 2 s2 + h: +-A[a_hi][i ^ k], sign a lane constant: byte address
-        // inside the item's +A / -A pair, without the step's 128 a_hi
-        uint32_t ak[16];
+    // A operand of term t: s2 = mfma16_k(t), k = 2 s2 + h: +-A[a_hi][i ^ k], sign a lane constant: byte address
+    // inside the item's +A / -A pair, without the step's 128 a_hi
+    uint32_t ak0[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int k = 2 * mfma16_k(t) + h;
-            const int a_lo = i ^ k;
-            int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
-            for (int pp = 1; pp < 5; ++pp)
-                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-            ak[t] = item_base + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
+    for (int t = 0; t < 16; ++t) {
+        const int k = 2 * mfma16_k(t) + h;
+        const int a_lo = i ^ k;
+        int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
+        for (int pp = 1; pp < 5; ++pp)
+            if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+        ak0[t] = item_base + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
+    }
+    // B side: byte offset of the lane's quad q inside the +B / -B pair = (lane constant) ^ (step constant); quads
+    // 0, 1 hold the even-|s2| words (|k| parity h), quads 2, 3 the odd ones: lanes with odd |c_hi| take the odd-|k|
+    // quads from the other image.  c_hi with a spare bit set: the uniform part u of the block sign rides in the popcount
+    const uint32_t b_base = item_base + 2u * NEG;
+    constexpr uint32_t zero_block = uint32_t(IPB) * uint32_t(item_stride) * 4u;
+    uint32_t bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = (uint32_t(c_hi) << 7) | (uint32_t((((h << 2) | q) ^ (c_hi >> 1)) & 7) << 4);
+        if ((__builtin_popcount(uint32_t(c_hi)) & 1) && (((q >> 1) ^ h) & 1)) bq[q] ^= NEG;
+    }
+    const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
+
+    for (int64_t g = blockIdx.x; g < num_groups; g += gridDim.x) {
+        const int64_t item0 = g * IPB;
+        const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
+        // ---- both operands of the group's items into their +/- images ----
+        if (fast) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int k = r % IPB, side = r / IPB;
+                if (k < nitems) {
+#pragma unroll
+                    for (int m = 0; m < MPR; ++m) {
+                        const float4 v = pf[r * MPR + m];
+                        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t w = mw[side][4 * m + c];
+                            float y = x[c];
+#if !GAAST_DENSE_NO_CANON
+                            if (side ? p.canon_right : p.canon_left) y = 0.f + y;   // the reference's zero-init + add_grades_from copy
+#endif
+                            const uint32_t yb = __float_as_uint(y) ^ (w & 0x80000000u);
+                            const uint32_t at = uint32_t(k) * uint32_t(item_stride * 4) + (side ? 2u * NEG : 0u) + (((w >> 16) & 0x7fffu) << 2);
+                            *(__attribute__((address_space(3))) uint32_t*)(lds + at) = yb;
+                            *(__attribute__((address_space(3))) uint32_t*)(lds + at + NEG) = yb ^ 0x80000000u;
+                        }
+                    }
+                }
+            }
+        } else {
+            if (!p.left_full || !p.right_full) {
+                for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
+                lds_barrier<THREADS>();
+            }
+            stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                           p.canon_left, smem, item_stride, nitems, tid);
+            stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
+            lds_barrier<THREADS>();
+            constexpr int quads_per_item = N >> 1;        // 16-byte pieces of +A and +B together
+            for (int e = tid; e < nitems * quads_per_item; e += THREADS) {
+                const int sit = e / quads_per_item, j = e - sit * quads_per_item;
+                const int src = sit * item_stride + (j << 2) + ((j << 2) < N ? 0 : N);
+                const float4v v = *reinterpret_cast<const float4v*>(smem + src);
+                *reinterpret_cast<float4v*>(smem + src + N) = -v;
+            }
         }
-        // B side: byte offset of the lane's quad q inside the +B / -B pair = (lane constant) ^ (step constant); quads
-        // 0, 1 hold the even-|s2| words (|k| parity h), quads 2, 3 the odd ones: lanes with odd |c_hi| take the odd-|k|
-        // quads from the other image.  c_hi with a spare bit set: the uniform part u of the block sign rides in the popcount
-        const uint32_t b_base = item_base + 2u * NEG;
-        const uint32_t zero_block = uint32_t(IPB) * uint32_t(item_stride) * 4u;
-        uint32_t bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bq[q] = (uint32_t(c_hi) << 7) | (uint32_t((((h << 2) | q) ^ (c_hi >> 1)) & 7) << 4);
-            if ((__builtin_popcount(uint32_t(c_hi)) & 1) && (((q >> 1) ^ h) & 1)) bq[q] ^= NEG;
-        }
-        const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
-        const uint32_t neg_shift = uint32_t(n + 2);
+        lds_barrier<THREADS>();
+        if (fast && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
 
-        float16v acc;
+        if (it < nitems) {
+            float16v acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            uint32_t ak[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ak[t] = ak0[t];
 
-        for (int a0 = 0; a0 < H; a0 += 8) {
+            for (int a0 = 0; a0 < H; a0 += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int a_hi = a0 + j;
-                // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
-                uint32_t sp = uint32_t(a_hi) >> 1;
-                sp ^= sp >> 1;
-                sp ^= sp >> 2;
-                sp ^= sp >> 4;
-                sp ^= sp >> 8;
-                const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-                const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
-                                    __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-                const uint32_t sbit = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) & 1u;
-                const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
-                const uint32_t sxs = (sbit << neg_shift) | sx;
-                uint32_t bw[16], aw[16];
+                for (int j = 0; j < 8; ++j) {
+                    const int a_hi = a0 + j;
+                    // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
+                    uint32_t sp = uint32_t(a_hi) >> 1;
+                    sp ^= sp >> 1;
+                    sp ^= sp >> 2;
+                    sp ^= sp >> 4;
+                    sp ^= sp >> 8;
+                    const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+                    const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
+                                        __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+                    const uint32_t sbit = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) & 1u;
+                    const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+                    const uint32_t sxs = (sbit << (n + 2)) | sx;
+                    uint32_t bw[16], aw[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t addr = b_base + (bq[q] ^ sxs);
-                    if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
-                    const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
-                    bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t addr = b_base + (bq[q] ^ sxs);
+                        if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
+                        const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
+                        bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
+                    asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
                 }
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
-                asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+                for (int t = 0; t < 16; ++t) ak[t] += 8u << 7;
             }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) ak[t] += 8u << 7;
-        }
 
-        // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
-        float* orow = p.out + (item0 + it) * p.out_stride;
-        const int32_t* om = p.out_map + (c_hi << 5);
+            // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
+            float* orow = p.out + (item0 + it) * p.out_stride;
+            const int32_t* om = p.out_map + (c_hi << 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-            store_result<float>(orow, om[c_lo], acc[r], p.beta);
+            for (int r = 0; r < 16; ++r) {
+                const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
+                store_result<float>(orow, om[c_lo], acc[r], p.beta);
+            }
         }
+        lds_barrier<THREADS>();   // the images are rewritten by the next group
     }
 }
 

@@ -238,10 +238,14 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 if (s.mfma32_pairs) {
                     s.lds = (size_t(s.items_per_block) * size_t(4 << n) + 16) * sizeof(float);
                     if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
-                    auto kernp = s.threads == 256 ? (s.degenerate ? &k_gp_mfma32p<true, 256> : &k_gp_mfma32p<false, 256>)
-                                                  : (s.degenerate ? &k_gp_mfma32p<true, 512> : &k_gp_mfma32p<false, 512>);
+                    using KernD = void (*)(DenseArgs<float>);
+                    const KernD kernp = n == 10   ? (s.degenerate ? &k_gp_mfma32p<true, 10> : &k_gp_mfma32p<false, 10>)
+                                        : n == 11 ? (s.degenerate ? &k_gp_mfma32p<true, 11> : &k_gp_mfma32p<false, 11>)
+                                        : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12> : &k_gp_mfma32p<false, 12>)
+                                                  : (s.degenerate ? &k_gp_mfma32p<true, 13> : &k_gp_mfma32p<false, 13>);
                     s.kern[0] = reinterpret_cast<const void*>(kernp);
-                    return allow_lds(s.kern[0], s.lds);
+                    if (int st = allow_lds(s.kern[0], s.lds)) return st;
+                    return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
                 }
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
