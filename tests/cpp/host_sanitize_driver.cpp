@@ -84,6 +84,20 @@ static uint32_t mfma_b_pos(uint32_t m) {
     return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
 }
 
+// k_gp_mfma16's B image: the words of block x stored even-|k| first, quads rotated (plan.cpp: mfma16_b_pos)
+static uint32_t mfma16_b_pos(uint32_t m) {
+    static const int word_of_k[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
+    const uint32_t x = m >> 4, w = uint32_t(word_of_k[m & 15]);
+    return (x << 4) | ((((w >> 2) ^ (x >> 2)) & 3) << 2) | (w & 3);
+}
+// k_gp_mfma32p's B image (plan.cpp: mfma32p_b_pos)
+static uint32_t mfma32p_b_pos(uint32_t m) {
+    static const int word_of_s[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
+    const uint32_t x = m >> 5, k = m & 31, w = uint32_t(word_of_s[k >> 1]);
+    const uint32_t lq = ((k & 1) << 2) | (w >> 2);
+    return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | (w & 3);
+}
+
 static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
                                              const char* expect_step) {
     gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
@@ -116,13 +130,20 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     // images in permuted-blade order
     std::vector<uint32_t> inv_vec(N), inv_b(N);
     for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
-    if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
+    if (st->mfma32_pairs) for (uint32_t m = 0; m < N; ++m) inv_b[mfma32p_b_pos(m)] = m;
+    else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
+    else if (st->use_mfma16) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16_b_pos(m)] = m;
     auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
         std::vector<double> img(N, 0.0);
         for (uint32_t w : map) {
             const uint32_t off = w & 0xffffu, pos = (w >> 16) & 0x7fffu;
-            const uint32_t blade = st->use_mfma ? (right ? inv_b[pos] : pos) : st->use_mfma16 ? (right ? inv_vec[pos] : pos) : inv_vec[pos];
-            img[blade] = (w >> 31) ? -row[off] : row[off];
+            const uint32_t blade = (st->use_mfma || st->use_mfma16) ? (right ? inv_b[pos] : pos) : inv_vec[pos];
+            uint32_t neg = w >> 31;
+            // the image-pair kernels keep the b_hi part of (-1)^(|a_hi| |b_lo|) in the B image (the kernel supplies the
+            // c_hi part): taken out again here, the plain formula below applies
+            if (right && (st->use_mfma16 || st->mfma32_pairs))
+                neg ^= uint32_t(__builtin_popcount(blade >> L) & __builtin_popcount(blade & ((1u << L) - 1u)) & 1);
+            img[blade] = neg ? -row[off] : row[off];
         }
         return img;
     };
