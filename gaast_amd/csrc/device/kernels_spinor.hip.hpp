@@ -98,6 +98,28 @@ __device__ __forceinline__ void wht(T (&v)[N]) {
     }
 }
 
+// The same transform on N values held as NP = N / 2 register pairs (v[2j], v[2j+1]): the butterflies of the first stage sit
+// inside a pair (one v_pk_add_f32 with op_sel picking the halves), every later stage adds / subtracts whole pairs --
+// N log2(N) / 2 packed instructions and no register moves; same operations in the same order as wht<N>.
+template <int NP>
+__device__ __forceinline__ void wht_pairs(float2v (&P)[NP]) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(P[j]) : "v"(P[j]));
+#pragma unroll
+    for (int hh = 1; hh < NP; hh <<= 1) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if ((j & hh) == 0) {
+                const float2v a = P[j], b = P[j | hh];
+                P[j] = a + b;
+                P[j | hh] = a - b;
+            }
+        }
+    }
+}
+__device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ------------------------------------------------------------------------------------------
 // n = 11, 12, f32.  ONE real plane per operand (derivation, numpy prototype and the exhaustive check over
 // signatures: tools/proto/spinor_single_plane.py; index bookkeeping: spinor_basis.hpp).
@@ -119,36 +141,43 @@ template <int LAMBIT>
 __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
+    lds_u8* lds = (lds_u8*)smem_raw;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     constexpr int LD = 65, P = 64 * LD;
     constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
 
-    uint32_t lm[8], rm[8], om[8];
+    // Vector instructions are what this kernel pays for (they take matrix-pipe time, LDS and global accesses do not), so
+    // the 16-bit table entries are expanded ONCE per launch into the form the per-item code consumes with two
+    // instructions per component: bit 31 = negate, bit 30 = nothing to store (result table), low 16 bits = byte offset.
+    // The offsets are LDS ADDRESSES (the planes' base and, for the right operand, its plane included), used as such.
+    uint32_t lm[16], rm[16], om[16];
+    const uint32_t lds0 = uint32_t(size_t(lds));
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
-        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
-        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
+    for (int u = 0; u < 16; ++u) {
+        const uint32_t el = p.left_map[tid + 256 * u], er = p.right_map[tid + 256 * u], eo = p.out_map[tid + 256 * u];
+        lm[u] = (el << 31) | (lds0 + (el & 0x7ffcu));
+        rm[u] = (er << 31) | (lds0 + uint32_t(64 * 65 * 4) + (er & 0x7ffcu));
+        om[u] = (eo << 31) | ((eo & 2u) << 29) | (lds0 + (eo & 0xfffcu));
     }
-    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
     float va[16], vb[16];
     const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
-    auto fetch = [&](int64_t item) {
-        const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride + tid;
-        const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride + tid;
+    auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's index: no per-access 64-bit arithmetic
+        const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride;
+        const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride;
         if (rows_full) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                va[u] = lrow[256 * u];
-                vb[u] = rrow[256 * u];
+                va[u] = lrow[tid + 256 * u];
+                vb[u] = rrow[tid + 256 * u];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int e = tid + 256 * u;
-                va[u] = e < p.left_len ? lrow[256 * u] : 0.f;
-                vb[u] = e < p.right_len ? rrow[256 * u] : 0.f;
+                va[u] = e < p.left_len ? lrow[e] : 0.f;
+                vb[u] = e < p.right_len ? rrow[e] : 0.f;
             }
         }
     };
@@ -160,38 +189,42 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 
     for (; item < p.batch; item += gridDim.x) {
 #pragma unroll
-        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(lm[u]), "+v"(rm[u]), "+v"(om[u]));
         // ---- 1. graded rows -> W[x][z], one word per component ----
+        // (no `0.0 + x` here: it only turns -0.0 into +0.0, and on this path, whose sums are re-ordered anyway, a zero of
+        //  either sign contributes the same to every sum)
         if (!p.left_full || !p.right_full) {
             for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.f;
             __syncthreads();
         }
         {
-            auto put = [&](float* plane, uint32_t e, float a, int canon) {
-                if (canon) a = 0.f + a;
-                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (e & 0x7ffcu)) = a;
-            };
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + P, entry(rm, u), vb[u], p.canon_right);
+                *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
+                *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
             }
         }
         __syncthreads();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
 
-        // ---- 2. one transform per row, two threads per row: fold bit 5 with sign (-1)^hb, 32 points ----
+        // ---- 2. one transform per row, two threads per row: fold bit 5 with sign (-1)^hb, 32 points as 16 pairs ----
         {
             const int hb = tid & 1;
             float* row = smem + (tid >> 7) * P + ((tid >> 1) & 63) * LD;
             const float sg = hb ? -1.f : 1.f;
-            float v[32];
+            const float2v sg2 = {sg, sg};
+            float2v v[16];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = fma_x(row[c + 32], sg, row[c]);   // sg = +-1: an exact product, one instruction
-            wht<32>(v);
+            for (int j = 0; j < 16; ++j) {   // sg = +-1: an exact product, one instruction
+                const float2v lo = {row[2 * j], row[2 * j + 1]}, hi = {row[2 * j + 32], row[2 * j + 33]};
+                v[j] = pk_fma(hi, sg2, lo);
+            }
+            wht_pairs<16>(v);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) row[c + 32 * hb] = v[c];   // the partner (adjacent lane) has read already
+            for (int j = 0; j < 16; ++j) {   // the partner (adjacent lane) has read already
+                row[2 * j + 32 * hb] = v[j][0];
+                row[2 * j + 1 + 32 * hb] = v[j][1];
+            }
         }
         __syncthreads();
 
@@ -218,15 +251,17 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 const float* A = smem;
                 const float* B = smem + P;
                 const uint32_t cb = uint32_t(16 * wave + i16);
-                const uint32_t gam = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;       // column bit 5
+                // sigma of the column (bit 5 of c, wave-uniform): q_B' = gsig q_B.  Applied as a factor of the sum p + q'
+                // (one fused multiply-add, exact) and, for Y = sum q_A' q_B', once to the finished accumulator below.
+                const float gsig = (p.has_alpha && (wave >> 1)) ? -1.f : 1.f;
 #pragma unroll
                 for (int s4 = 0; s4 < 16; ++s4) {
                     const uint32_t k = uint32_t(4 * s4 + kq);
                     const bool hi = ((4 * s4) & LAM) != 0;                               // k has the lambda bit: partner below
                     const uint32_t ib = (cb ^ k) * LD + k;
                     const float pb = B[ib];
-                    float qb = hi ? B[ib - LAM] : B[ib + LAM];
-                    qb = __uint_as_float(__float_as_uint(qb) ^ gam);
+                    const float qb = hi ? B[ib - LAM] : B[ib + LAM];
+                    const float sb = fma_x(qb, gsig, pb);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const uint32_t ra = uint32_t(half_row(16 * t + i16));
@@ -237,15 +272,19 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                         qa = __uint_as_float(__float_as_uint(qa) ^ rho);
                         gx[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, gx[t], 0, 0, 0);
                         gy[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, qb, gy[t], 0, 0, 0);
-                        gz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, pb + qb, gz[t], 0, 0, 0);
+                        gz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa + qa, sb, gz[t], 0, 0, 0);
                     }
                     if (s4 == 7) {   // real part of the k_5 = 0 half; the accumulators keep running
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) bank_re[t][r] = gz[t][r] - gx[t][r] - gy[t][r];
+                            for (int r = 0; r < 4; ++r) bank_re[t][r] = fma_x(-gsig, gy[t][r], gz[t][r] - gx[t][r]);
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gy[t][r] *= gsig;
             }
             __syncthreads();  // every wave is done reading the operand planes
             // ---- 4'. C and its mirror image -> LDS, diagonals indexed by row: S[r ^ c][r] = C[r][c] ----
@@ -339,32 +378,43 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
             const float* q = smem + f * P + x * LD;
             const float sc = 1.0f / 128.0f;                // 2^-6 of the transform, 1/2 of E E
             const float s1 = h1 ? -sc : sc, s2f = h2 ? -1.f : 1.f;
-            float v[16];
+            const float2v sc2 = {sc, sc}, s12 = {s1, s1}, s22 = {s2f, s2f};
+            float2v v[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int jp = 0; jp < 8; ++jp) {
                 // sc, s1 = +-2^-7, s2f = +-1: every product is exact, the fused forms round like the unfused ones
-                const float lo = fma_x(q[j | (1 << B1)], s1, q[j] * sc);
-                const float hi = fma_x(q[j | (1 << B1) | (1 << B2)], s1, q[j | (1 << B2)] * sc);
-                v[j] = fma_x(hi, s2f, lo);
+                const int j = 2 * jp;
+                const float2v q00 = {q[j], q[j + 1]}, q10 = {q[j | (1 << B1)], q[(j | (1 << B1)) + 1]};
+                const float2v q01 = {q[j | (1 << B2)], q[(j | (1 << B2)) + 1]};
+                const float2v q11 = {q[j | (1 << B1) | (1 << B2)], q[(j | (1 << B1) | (1 << B2)) + 1]};
+                const float2v lo = pk_fma(q10, s12, q00 * sc2);
+                const float2v hi = pk_fma(q11, s12, q01 * sc2);
+                v[jp] = pk_fma(hi, s22, lo);
             }
-            wht<16>(v);
+            wht_pairs<8>(v);
             float* o = smem + x * LD + (h1 << B1) + (h2 << B2);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 16; ++j) o[j] = v[j];      // the four threads of a row are adjacent lanes
+            for (int jp = 0; jp < 8; ++jp) {               // the four threads of a row are adjacent lanes
+                o[2 * jp] = v[jp][0];
+                o[2 * jp + 1] = v[jp][1];
+            }
         }
         __syncthreads();
         {
-            float* orow = static_cast<float*>(p.out) + item * p.out_stride + tid;
+            float* orow = static_cast<float*>(p.out) + item * p.out_stride;   // uniform base + the thread's index
+            if (p.out_full && !p.beta) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t eo = entry(om, u);
-                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
-                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
-                if (p.out_full && !p.beta) {
-                    orow[256 * u] = val;
-                } else if (!(eo & 2u)) {
-                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t val = *(const lds_u32*)(om[u] & 0x3fffffu) ^ (om[u] & 0x80000000u);
+                    orow[tid + 256 * u] = __uint_as_float(val);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t eo = om[u];
+                    const float val = __uint_as_float(*(const lds_u32*)(eo & 0x3fffffu) ^ (eo & 0x80000000u));
+                    if (!(eo & 0x40000000u)) orow[tid + 256 * u] = p.beta ? orow[tid + 256 * u] + val : val;
                 }
             }
         }
