@@ -137,13 +137,18 @@ __device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c) { ret
 // the other of {4,5} and transform the remaining 16 points.
 // LAMBIT = -1: lambda = 0 (q = p, every phase of a row is the same).
 // ------------------------------------------------------------------------------------------
-template <int LAMBIT>
+// FAST: both operands and the result hold every blade in 16-byte aligned rows and nothing is accumulated (the host
+// checks): one path through the loop, so that the wait for the prefetched rows can leave the stores in flight.
+template <int LAMBIT, bool FAST>
 __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    constexpr int LD = 65, P = 64 * LD;
+    constexpr int LD = 65, P0 = 64 * LD;
+    // the second plane 16 words further: the inverse transform reads both planes in one instruction (lanes of a row
+    // differ in the plane), 16 rows x 2 planes then cover the 32 banks
+    constexpr int P = P0 + 16;
     constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -152,60 +157,76 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     // the 16-bit table entries are expanded ONCE per launch into the form the per-item code consumes with two
     // instructions per component: bit 31 = negate, bit 30 = nothing to store (result table), low 16 bits = byte offset.
     // The offsets are LDS ADDRESSES (the planes' base and, for the right operand, its plane included), used as such.
+    // Register u of a thread holds component 4 tid + (u & 3) + 1024 (u >> 2) of a row: four 16-byte pieces per row and
+    // thread (a quarter of the memory instructions of a dword-per-lane split).
     uint32_t lm[16], rm[16], om[16];
     const uint32_t lds0 = uint32_t(size_t(lds));
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const uint32_t el = p.left_map[tid + 256 * u], er = p.right_map[tid + 256 * u], eo = p.out_map[tid + 256 * u];
+        const int e = 4 * tid + (u & 3) + 1024 * (u >> 2);
+        const uint32_t el = p.left_map[e], er = p.right_map[e], eo = p.out_map[e];
         lm[u] = (el << 31) | (lds0 + (el & 0x7ffcu));
-        rm[u] = (er << 31) | (lds0 + uint32_t(64 * 65 * 4) + (er & 0x7ffcu));
+        rm[u] = (er << 31) | (lds0 + uint32_t(P * 4) + (er & 0x7ffcu));
         om[u] = (eo << 31) | ((eo & 2u) << 29) | (lds0 + (eo & 0xfffcu));
     }
     float va[16], vb[16];
-    const bool rows_full = p.left_len == 4096 && p.right_len == 4096;
+    auto aligned16 = [](const void* ptr, int64_t stride) { return ((reinterpret_cast<uintptr_t>(ptr) | uintptr_t(stride * 4)) & 15u) == 0; };
+    const bool rows_vec = FAST || (((p.left_len | p.right_len) & 3) == 0 && aligned16(p.left, p.left_stride) && aligned16(p.right, p.right_stride));
+    const bool out_vec = FAST || (p.out_full && !p.beta && aligned16(p.out, p.out_stride));
     auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's index: no per-access 64-bit arithmetic
         const float* lrow = static_cast<const float*>(p.left) + item * p.left_stride;
         const float* rrow = static_cast<const float*>(p.right) + item * p.right_stride;
-        if (rows_full) {
+        if (rows_vec) {   // rows shorter than 4096 (odd n: the subalgebra of n + 1) end on a piece boundary
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                va[u] = lrow[tid + 256 * u];
-                vb[u] = rrow[tid + 256 * u];
+            for (int u4 = 0; u4 < 4; ++u4) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+                if (FAST || p.left_len == 4096 || 4 * tid + 1024 * u4 < p.left_len) x = reinterpret_cast<const float4*>(lrow)[tid + 256 * u4];
+                if (FAST || p.right_len == 4096 || 4 * tid + 1024 * u4 < p.right_len) y = reinterpret_cast<const float4*>(rrow)[tid + 256 * u4];
+                va[4 * u4 + 0] = x.x; va[4 * u4 + 1] = x.y; va[4 * u4 + 2] = x.z; va[4 * u4 + 3] = x.w;
+                vb[4 * u4 + 0] = y.x; vb[4 * u4 + 1] = y.y; vb[4 * u4 + 2] = y.z; vb[4 * u4 + 3] = y.w;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int e = tid + 256 * u;
+                const int e = 4 * tid + (u & 3) + 1024 * (u >> 2);
                 va[u] = e < p.left_len ? lrow[e] : 0.f;
                 vb[u] = e < p.right_len ? rrow[e] : 0.f;
             }
         }
     };
-    int64_t item = blockIdx.x;
-    if (item < p.batch) fetch(item);
     // sigma of the tile's rows / columns and the sign of the second k half: wave-uniform
     const uint32_t rho_mask = (p.has_alpha && (wave >> 1)) ? 0x80000000u : 0u;
     const uint32_t gam_mask = (p.has_alpha && (wave & 1)) ? 0x80000000u : 0u;
 
-    for (; item < p.batch; item += gridDim.x) {
+    // ---- 1. graded rows -> W[x][z], one word per component ----
+    // (no `0.0 + x` here: it only turns -0.0 into +0.0, and on this path, whose sums are re-ordered anyway, a zero of
+    //  either sign contributes the same to every sum)
+    auto stage = [&]() {
+        if (!FAST && (!p.left_full || !p.right_full)) {
+            for (int i = tid; i < P0 + P; i += 256) smem[i] = 0.f;
+            lds_barrier<256>();
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
+            *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
+        }
+    };
+    // The loop is rotated: the rows of item i + 1 are staged at the END of item i's pass, after its result rows were
+    // stored.  Loads and stores share one in-order counter (vmcnt); with the staging at the top of the loop the wait for
+    // the prefetched rows sits where the first item's path (loads issued last) and the loop's path (stores issued last)
+    // merge and becomes vmcnt(0): the round trip of the previous item's stores on every item.  Here the wait has one
+    // path -- loads, then stores -- and leaves the stores in flight.
+    int64_t item = blockIdx.x;
+    if (item >= p.batch) return;
+    fetch(item);
+    stage();
+    for (;;) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(lm[u]), "+v"(rm[u]), "+v"(om[u]));
-        // ---- 1. graded rows -> W[x][z], one word per component ----
-        // (no `0.0 + x` here: it only turns -0.0 into +0.0, and on this path, whose sums are re-ordered anyway, a zero of
-        //  either sign contributes the same to every sum)
-        if (!p.left_full || !p.right_full) {
-            for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.f;
-            __syncthreads();
-        }
-        {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
-                *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
-            }
-        }
-        __syncthreads();
-        if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
+        lds_barrier<256>();
+        const bool more = item + gridDim.x < p.batch;
+        if (more) fetch(item + gridDim.x);
 
         // ---- 2. one transform per row, two threads per row: fold bit 5 with sign (-1)^hb, 32 points as 16 pairs ----
         {
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 row[2 * j + 1 + 32 * hb] = v[j][1];
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
 
         if constexpr (LAMBIT >= 0 && GAAST_SPINOR_HALF) {
             // ---- 3'. HALF the product.  With lambda != 0 the representation has a real structure:
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) gy[t][r] *= gsig;
             }
-            __syncthreads();  // every wave is done reading the operand planes
+            lds_barrier<256>();  // every wave is done reading the operand planes
             // ---- 4'. C and its mirror image -> LDS, diagonals indexed by row: S[r ^ c][r] = C[r][c] ----
             {
                 const int c = 16 * wave + i16;
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                         q[P + LAM] = __uint_as_float(__float_as_uint(im) ^ sg ^ 0x80000000u);
                     }
             }
-            __syncthreads();
+            lds_barrier<256>();
         } else {
         // ---- 3. the product: X = p r, Y = q' s', Z = (p+q')(r+s'), k_5 = 0 first ----
         const int i = lane & 31, h = lane >> 5;
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();  // every wave is done reading the operand planes
+        lds_barrier<256>();  // every wave is done reading the operand planes
 
         // ---- 4. C -> LDS, diagonals indexed by row: S[r ^ c][r] = C[r][c]; plane 0 real, plane 1 imaginary ----
         {
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
         }
         // ---- 5. four threads per row: fold the plane that holds this quarter's components ----
         {
@@ -400,25 +421,32 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 o[2 * jp + 1] = v[jp][1];
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
         {
             float* orow = static_cast<float*>(p.out) + item * p.out_stride;   // uniform base + the thread's index
-            if (p.out_full && !p.beta) {
+            if (out_vec) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const uint32_t val = *(const lds_u32*)(om[u] & 0x3fffffu) ^ (om[u] & 0x80000000u);
-                    orow[tid + 256 * u] = __uint_as_float(val);
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
+                    reinterpret_cast<float4*>(orow)[tid + 256 * u4] =
+                        make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t eo = om[u];
+                    const int e = 4 * tid + (u & 3) + 1024 * (u >> 2);
                     const float val = __uint_as_float(*(const lds_u32*)(eo & 0x3fffffu) ^ (eo & 0x80000000u));
-                    if (!(eo & 0x40000000u)) orow[tid + 256 * u] = p.beta ? orow[tid + 256 * u] + val : val;
+                    if (!(eo & 0x40000000u)) orow[e] = p.beta ? orow[e] + val : val;
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<256>();   // every wave is done with the planes
+        if (!more) break;
+        item += gridDim.x;
+        stage();
     }
 }
 
@@ -477,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
         // ---- 1. graded rows -> W[x][z] ----
         if (!p.left_full || !p.right_full) {
             for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.0;
-            __syncthreads();
+            lds_barrier<256>();
         }
         {
             auto put = [&](double* plane, uint32_t e, double a, int canon) {
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                 put(smem + P, entry(rm, u), vb[u], p.canon_right);
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
 
         // ---- 2. one transform per row, two threads per row ----
         {
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
 #pragma unroll
             for (int c = 0; c < 32; ++c) row[c + 32 * hb] = v[c];
         }
-        __syncthreads();
+        lds_barrier<256>();
 
         if constexpr (LAMBIT >= 0 && GAAST_SPINOR_HALF) {
             // ---- 3'. half the product (rows with the lambda bit clear), mirrored: see k_gp_spinor12s.  Wave w owns the 32
@@ -565,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier<256>();
             // ---- 4'. C and its mirror image -> LDS; accumulator layout: col = lane & 15, row = (lane >> 4) + 4 r ----
             {
                 const int c = 16 * wave + i;
@@ -640,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
 
         // ---- 4. C -> LDS, diagonals indexed by row; accumulator layout: col = lane & 15, row = (lane >> 4) + 4 r ----
 #pragma unroll
@@ -666,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
             }
         }
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // the accumulators are dead: room for the rows
-        __syncthreads();
+        lds_barrier<256>();
         // ---- 5. four threads per row fold the plane that holds this quarter's components ----
         {
             constexpr int B1 = LAMBIT == 4 ? 4 : 5, B2 = LAMBIT == 4 ? 5 : 4;
@@ -700,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) o[j] = v[j];
         }
-        __syncthreads();
+        lds_barrier<256>();
         {
             double* orow = outp + item * p.out_stride + tid;
 #pragma unroll
@@ -715,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<256>();
     }
 }
 
@@ -782,7 +810,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
         for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
         if (!p.left_full || !p.right_full) {
             for (int j = lane; j < 2 * P; j += 64) smem[j] = 0.f;
-            __syncthreads();
+            lds_barrier<64>();
         }
         {
             auto put = [&](float* plane, uint32_t e, float a, int canon) {
@@ -796,7 +824,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 put(smem + P, entry(rm, u), vb[u], p.canon_right);
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
 
         // one transform per row, two threads per row: (operand, x, half) = 4 D half-rows over 64 lanes
@@ -813,7 +841,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
 #pragma unroll
             for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
         }
-        __syncthreads();
+        lds_barrier<64>();
 
         if constexpr (M == 5 && LAMBIT >= 0 && GAAST_SPINOR_HALF) {
             // half the product (the 16 rows with the lambda bit clear), mirrored: see k_gp_spinor12s.  Two 16 x 16 column
@@ -858,7 +886,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                         for (int r = 0; r < 4; ++r) hbank[t][r] = hz[t][r] - hx[t][r] - hy[t][r];
                 }
             }
-            __syncthreads();
+            lds_barrier<64>();
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -875,7 +903,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                     q[LAM] = __uint_as_float(__float_as_uint(re) ^ sg);
                     q[P + LAM] = __uint_as_float(__float_as_uint(im) ^ sg ^ 0x80000000u);
                 }
-            __syncthreads();
+            lds_barrier<64>();
         } else {
         acc_t gx, gy, gz, bank_re;
 #pragma unroll
@@ -912,7 +940,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 for (int r = 0; r < NACC; ++r) bank_re[r] = LAMBIT >= 0 ? gz[r] - gx[r] - gy[r] : gx[r];
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int rr = M == 4 ? 4 * kq + r : (r & 3) + 8 * (r >> 2) + 4 * kq;
@@ -927,7 +955,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 smem[P + (rr ^ i) * LD + rr] = gx[r] - gy[r];
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
         }
         // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
         {
@@ -952,7 +980,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 }
                 wht<Q>(v[j]);
             }
-            __syncthreads();   // every pass has read its planes before any result lands in plane 0
+            lds_barrier<64>();   // every pass has read its planes before any result lands in plane 0
 #pragma unroll
             for (int j = 0; j < INV_PASSES; ++j) {
                 const int tix = lane + 64 * j;
@@ -962,7 +990,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 for (int c = 0; c < Q; ++c) o[c] = v[j][c];
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
         {
             float* orow = outp + item * p.out_stride + lane;
 #pragma unroll
@@ -977,7 +1005,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
     }
 }
 
@@ -1031,7 +1059,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
         for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
         if (!p.left_full || !p.right_full) {
             for (int j = lane; j < 2 * P; j += 64) smem[j] = 0.0;
-            __syncthreads();
+            lds_barrier<64>();
         }
         {
             auto put = [&](double* plane, uint32_t e, double a, int canon) {
@@ -1045,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 put(smem + P, entry(rm, u), vb[u], p.canon_right);
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
 
         // one transform per row, two threads per row: (operand, x, half) = 4 D half-rows over 64 lanes
@@ -1062,7 +1090,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
 #pragma unroll
             for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
         }
-        __syncthreads();
+        lds_barrier<64>();
 
         constexpr bool HALF = M == 5 && LAMBIT >= 0 && GAAST_SPINOR_HALF;   // rows with the lambda bit clear, mirrored (k_gp_spinor12s)
         constexpr int TR = HALF ? 1 : TB;                                    // row tiles
@@ -1118,7 +1146,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                     for (int r = 0; r < 4; ++r) bank_re[t][r] = LAMBIT >= 0 ? gz[t][r] - gx[t][r] - gy[t][r] : gx[t][r];
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
 #pragma unroll
         for (int rb = 0; rb < TR; ++rb)
 #pragma unroll
@@ -1145,7 +1173,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                         q[P + LAM] = neg ? im : -im;
                     }
                 }
-        __syncthreads();
+        lds_barrier<64>();
         // four threads per row: fold bits B1 (lambda's, or the top one) and B2, transform the rest
         {
             constexpr int B1 = LAMBIT == M - 2 ? M - 2 : M - 1, B2 = LAMBIT == M - 2 ? M - 1 : M - 2;
@@ -1169,7 +1197,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 }
                 wht<Q, double>(v[j]);
             }
-            __syncthreads();   // every pass has read its planes before any result lands in plane 0
+            lds_barrier<64>();   // every pass has read its planes before any result lands in plane 0
 #pragma unroll
             for (int j = 0; j < INV_PASSES; ++j) {
                 const int tix = lane + 64 * j;
@@ -1179,7 +1207,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 for (int c = 0; c < Q; ++c) o[c] = v[j][c];
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
         {
             double* orow = outp + item * p.out_stride + lane;
 #pragma unroll
@@ -1194,7 +1222,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1d(SpinorArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier<64>();
     }
 }
 

@@ -216,13 +216,18 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             using KernS = void (*)(SpinorArgs);
             const int m = s.use_spinor;
             const size_t D = size_t(1) << m, plane = (D * (D + 1) + 63) / 64 * 64;
-            s.lds = (m == 6 ? 2 * plane : 2 * D * (D + 1)) * sizeof(T);
+            s.lds = (m == 6 ? 2 * plane + (is_f64 ? 0 : 16) : 2 * D * (D + 1)) * sizeof(T);   // k_gp_spinor12s: second plane 16 words further
             const int lb5 = s.spinor_lam_bit;
             KernS kern = nullptr;
             if (is_f64 && m == 6) kern = lb5 == 5 ? &k_gp_spinor12d<5> : lb5 == 4 ? &k_gp_spinor12d<4> : &k_gp_spinor12d<-1>;
             else if (is_f64 && m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1d<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1d<5, 3> : &k_gp_spinor_wave1d<5, -1>;
             else if (is_f64) kern = lb5 == 3 ? &k_gp_spinor_wave1d<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1d<4, 2> : &k_gp_spinor_wave1d<4, -1>;
-            else if (m == 6) kern = lb5 == 5 ? &k_gp_spinor12s<5> : lb5 == 4 ? &k_gp_spinor12s<4> : &k_gp_spinor12s<-1>;
+            else if (m == 6) {
+                kern = lb5 == 5 ? &k_gp_spinor12s<5, false> : lb5 == 4 ? &k_gp_spinor12s<4, false> : &k_gp_spinor12s<-1, false>;
+                const KernS fast = lb5 == 5 ? &k_gp_spinor12s<5, true> : lb5 == 4 ? &k_gp_spinor12s<4, true> : &k_gp_spinor12s<-1, true>;
+                s.kern[1] = reinterpret_cast<const void*>(fast);   // full, aligned rows on both sides and in the result
+                if (int st = allow_lds(s.kern[1], s.lds)) return st;
+            }
             else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
             else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;
             s.kern[0] = reinterpret_cast<const void*>(kern);
@@ -421,7 +426,12 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             using KernS = void (*)(SpinorArgs);
             int64_t blocks = int64_t(g_num_cu) * s.blocks_per_cu;
             if (blocks > batch) blocks = batch;
-            hipLaunchKernelGGL(reinterpret_cast<KernS>(const_cast<void*>(s.kern[0])), dim3(unsigned(blocks)),
+            auto aligned16 = [](const void* ptr, int64_t stride) {
+                return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((size_t(stride) * sizeof(T)) % 16 == 0);
+            };
+            const bool fast = s.kern[1] && s.left_full && s.right_full && s.out_full && !s.beta && q.left_len == 4096 && q.right_len == 4096 &&
+                              aligned16(a.ptr, a.stride) && aligned16(b.ptr, b.stride) && aligned16(res.ptr, res.stride);
+            hipLaunchKernelGGL(reinterpret_cast<KernS>(const_cast<void*>(s.kern[fast ? 1 : 0])), dim3(unsigned(blocks)),
                                dim3(unsigned(s.threads)), s.lds, g_stream, q);
             break;
         }
