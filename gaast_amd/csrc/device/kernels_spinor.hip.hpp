@@ -771,31 +771,41 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
     const float* right = static_cast<const float*>(p.right);
     float* outp = static_cast<float*>(p.out);
 
-    uint32_t lm[EPL / 2], rm[EPL / 2], om[EPL / 2];
+    // As in k_gp_spinor12s: the 16-bit table entries expanded once per launch (bit 31 = negate, bit 30 = nothing to store,
+    // low bits = LDS address), register u of a lane = component 4 lane + (u & 3) + 256 (u >> 2): 16-byte pieces.
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    uint32_t lm[EPL], rm[EPL], om[EPL];
+    const uint32_t lds0 = uint32_t(size_t((lds_u8*)smem_raw));
 #pragma unroll
-    for (int w = 0; w < EPL / 2; ++w) {
-        lm[w] = uint32_t(p.left_map[lane + 128 * w]) | (uint32_t(p.left_map[lane + 128 * w + 64]) << 16);
-        rm[w] = uint32_t(p.right_map[lane + 128 * w]) | (uint32_t(p.right_map[lane + 128 * w + 64]) << 16);
-        om[w] = uint32_t(p.out_map[lane + 128 * w]) | (uint32_t(p.out_map[lane + 128 * w + 64]) << 16);
+    for (int u = 0; u < EPL; ++u) {
+        const int e = 4 * lane + (u & 3) + 256 * (u >> 2);
+        const uint32_t el = p.left_map[e], er = p.right_map[e], eo = p.out_map[e];
+        lm[u] = (el << 31) | (lds0 + (el & 0x7ffcu));
+        rm[u] = (er << 31) | (lds0 + uint32_t(P * 4) + (er & 0x7ffcu));
+        om[u] = (eo << 31) | ((eo & 2u) << 29) | (lds0 + (eo & 0xfffcu));
     }
-    auto entry = [](const uint32_t (&m)[EPL / 2], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
     float va[EPL], vb[EPL];
-    const bool rows_full = p.left_len == NE && p.right_len == NE;
-    auto fetch = [&](int64_t item) {
-        const float* lrow = left + item * p.left_stride + lane;
-        const float* rrow = right + item * p.right_stride + lane;
-        if (rows_full) {
+    auto aligned16 = [](const void* ptr, int64_t stride) { return ((reinterpret_cast<uintptr_t>(ptr) | uintptr_t(stride * 4)) & 15u) == 0; };
+    const bool rows_vec = ((p.left_len | p.right_len) & 3) == 0 && aligned16(p.left, p.left_stride) && aligned16(p.right, p.right_stride);
+    const bool out_vec = p.out_full && !p.beta && aligned16(p.out, p.out_stride);
+    auto fetch = [&](int64_t item) {   // (uniform) row base + the lane's index
+        const float* lrow = left + item * p.left_stride;
+        const float* rrow = right + item * p.right_stride;
+        if (rows_vec) {   // shorter rows (odd n: the subalgebra of n + 1) end on a piece boundary
 #pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                va[u] = lrow[64 * u];
-                vb[u] = rrow[64 * u];
+            for (int u4 = 0; u4 < EPL / 4; ++u4) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+                if (p.left_len == NE || 4 * lane + 256 * u4 < p.left_len) x = reinterpret_cast<const float4*>(lrow)[lane + 64 * u4];
+                if (p.right_len == NE || 4 * lane + 256 * u4 < p.right_len) y = reinterpret_cast<const float4*>(rrow)[lane + 64 * u4];
+                va[4 * u4 + 0] = x.x; va[4 * u4 + 1] = x.y; va[4 * u4 + 2] = x.z; va[4 * u4 + 3] = x.w;
+                vb[4 * u4 + 0] = y.x; vb[4 * u4 + 1] = y.y; vb[4 * u4 + 2] = y.z; vb[4 * u4 + 3] = y.w;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
-                const int e = lane + 64 * u;
-                va[u] = e < p.left_len ? lrow[64 * u] : 0.f;
-                vb[u] = e < p.right_len ? rrow[64 * u] : 0.f;
+                const int e = 4 * lane + (u & 3) + 256 * (u >> 2);
+                va[u] = e < p.left_len ? lrow[e] : 0.f;
+                vb[u] = e < p.right_len ? rrow[e] : 0.f;
             }
         }
     };
@@ -807,22 +817,16 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
 
     for (; item < p.batch; item += gridDim.x) {
 #pragma unroll
-        for (int w = 0; w < EPL / 2; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
+        for (int u = 0; u < EPL; ++u) asm volatile("" : "+v"(lm[u]), "+v"(rm[u]), "+v"(om[u]));
         if (!p.left_full || !p.right_full) {
             for (int j = lane; j < 2 * P; j += 64) smem[j] = 0.f;
             lds_barrier<64>();
         }
-        {
-            auto put = [&](float* plane, uint32_t e, float a, int canon) {
-                if (canon) a = 0.f + a;
-                a = __uint_as_float(__float_as_uint(a) ^ (e << 31));
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (e & 0x7ffcu)) = a;
-            };
+        // (no `0.0 + x`: on this path a zero of either sign contributes the same to every sum)
 #pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + P, entry(rm, u), vb[u], p.canon_right);
-            }
+        for (int u = 0; u < EPL; ++u) {
+            *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
+            *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
         }
         lds_barrier<64>();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
@@ -834,12 +838,19 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
             const int hb = hidx & 1;
             float* row = smem + (hidx >> (M + 1)) * P + ((hidx >> 1) & (D - 1)) * LD;
             const float sg = hb ? -1.f : 1.f;
-            float v[D / 2];
+            const float2v sg2 = {sg, sg};
+            float2v v[D / 4];
 #pragma unroll
-            for (int c = 0; c < D / 2; ++c) v[c] = fma_x(row[c + D / 2], sg, row[c]);   // sg = +-1: an exact product, one instruction
-            wht<D / 2>(v);
+            for (int c = 0; c < D / 4; ++c) {   // sg = +-1: an exact product, one instruction
+                const float2v lo = {row[2 * c], row[2 * c + 1]}, up = {row[2 * c + D / 2], row[2 * c + 1 + D / 2]};
+                v[c] = pk_fma(up, sg2, lo);
+            }
+            wht_pairs<D / 4>(v);
 #pragma unroll
-            for (int c = 0; c < D / 2; ++c) row[c + (D / 2) * hb] = v[c];
+            for (int c = 0; c < D / 4; ++c) {
+                row[2 * c + (D / 2) * hb] = v[c][0];
+                row[2 * c + 1 + (D / 2) * hb] = v[c][1];
+            }
         }
         lds_barrier<64>();
 
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
         {
             constexpr int B1 = LAMBIT == M - 2 ? M - 2 : M - 1, B2 = LAMBIT == M - 2 ? M - 1 : M - 2;
             constexpr int Q = D / 4;
-            float v[INV_PASSES][Q];
+            float2v v[INV_PASSES][Q / 2];
 #pragma unroll
             for (int j = 0; j < INV_PASSES; ++j) {
                 const int tix = lane + 64 * j;
@@ -971,14 +982,19 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 const float* q = smem + f * P + x * LD;
                 const float sc = 0.5f / float(D);
                 const float s1 = h1 ? -sc : sc, s2f = h2 ? -1.f : 1.f;
+                const float2v sc2 = {sc, sc}, s12 = {s1, s1}, s22 = {s2f, s2f};
 #pragma unroll
-                for (int c = 0; c < Q; ++c) {
+                for (int cp = 0; cp < Q / 2; ++cp) {
                     // sc, s1 = +-2^-k, s2f = +-1: every product is exact, the fused forms round like the unfused ones
-                    const float lo = fma_x(q[c | (1 << B1)], s1, q[c] * sc);
-                    const float up = fma_x(q[c | (1 << B1) | (1 << B2)], s1, q[c | (1 << B2)] * sc);
-                    v[j][c] = fma_x(up, s2f, lo);
+                    const int c = 2 * cp;
+                    const float2v q00 = {q[c], q[c + 1]}, q10 = {q[c | (1 << B1)], q[(c | (1 << B1)) + 1]};
+                    const float2v q01 = {q[c | (1 << B2)], q[(c | (1 << B2)) + 1]};
+                    const float2v q11 = {q[c | (1 << B1) | (1 << B2)], q[(c | (1 << B1) | (1 << B2)) + 1]};
+                    const float2v lo = pk_fma(q10, s12, q00 * sc2);
+                    const float2v up = pk_fma(q11, s12, q01 * sc2);
+                    v[j][cp] = pk_fma(up, s22, lo);
                 }
-                wht<Q>(v[j]);
+                wht_pairs<Q / 2>(v[j]);
             }
             lds_barrier<64>();   // every pass has read its planes before any result lands in plane 0
 #pragma unroll
@@ -987,21 +1003,31 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 const int x = tix >> 2, h1 = (tix >> 1) & 1, h2 = tix & 1;
                 float* o = smem + x * LD + (h1 << B1) + (h2 << B2);
 #pragma unroll
-                for (int c = 0; c < Q; ++c) o[c] = v[j][c];
+                for (int cp = 0; cp < Q / 2; ++cp) {
+                    o[2 * cp] = v[j][cp][0];
+                    o[2 * cp + 1] = v[j][cp][1];
+                }
             }
         }
         lds_barrier<64>();
         {
-            float* orow = outp + item * p.out_stride + lane;
+            float* orow = outp + item * p.out_stride;   // (uniform) row base + the lane's index
+            if (out_vec) {
 #pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                const uint32_t eo = entry(om, u);
-                float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + (eo & 0xfffcu));
-                val = __uint_as_float(__float_as_uint(val) ^ (eo << 31));
-                if (p.out_full && !p.beta) {
-                    orow[64 * u] = val;
-                } else if (!(eo & 2u)) {
-                    orow[64 * u] = p.beta ? orow[64 * u] + val : val;
+                for (int u4 = 0; u4 < EPL / 4; ++u4) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
+                    reinterpret_cast<float4*>(orow)[lane + 64 * u4] =
+                        make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const uint32_t eo = om[u];
+                    const int e = 4 * lane + (u & 3) + 256 * (u >> 2);
+                    const float val = __uint_as_float(*(const lds_u32*)(eo & 0x3fffffu) ^ (eo & 0x80000000u));
+                    if (!(eo & 0x40000000u)) orow[e] = p.beta ? orow[e] + val : val;
                 }
             }
         }
