@@ -19,6 +19,9 @@
 #ifndef GAAST_MFMA16_PRIO_RAMP
 #define GAAST_MFMA16_PRIO_RAMP 0
 #endif
+#ifndef GAAST_SLOT_PRIO        /* persistent matrix-core kernels: a fixed, different priority per wave slot of a SIMD */
+#define GAAST_SLOT_PRIO 0
+#endif
 #define GAAST_STR2(x) #x
 #define GAAST_STR(x) GAAST_STR2(x)
 
@@ -633,6 +636,18 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
 }
 
+// Waves that share a SIMD start a persistent kernel together and, being identical, stay in phase: they stage their
+// operands at the same time (matrix pipe idle) and then compete for the pipe.  A fixed, DIFFERENT priority per wave slot
+// of the SIMD (HW_ID[3:0]) lets one wave run ahead until the phases alternate.
+__device__ __forceinline__ void wave_slot_priority() {
+#if GAAST_SLOT_PRIO
+    const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // hwreg(HW_REG_HW_ID, 0, 4)
+    if (slot == 0) __builtin_amdgcn_s_setprio(3);
+    else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 // Workgroup barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and
 // loads (vmcnt(0)): between the groups of a persistent workgroup that is the round trip of the result rows to HBM.
 // A single-wave workgroup needs no barrier at all: the LDS executes a wave's instructions in order.
@@ -693,6 +708,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
     const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full;
+    wave_slot_priority();
 
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
 
@@ -906,6 +922,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
     static_assert(COUNT4 == THREADS, "one 16-byte piece of each row per thread");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
+    wave_slot_priority();
 
     // the 16 spare words of every item: zero for the whole launch
     if (tid < 16 * IPB) smem[(tid >> 4) * item_stride + 4 * N + (tid & 15)] = 0.f;
@@ -1044,7 +1061,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
         // (no vector instruction in the loop); n = 9 would need 128: recomputed per group, 6 instructions per step
         uint32_t sign_now = sign_bits;
         if (NDIM > 8) asm volatile("" : "+v"(sign_now));
-#if GAAST_MFMA16_SETPRIO
+#if GAAST_MFMA16_SETPRIO && !GAAST_SLOT_PRIO
         __builtin_amdgcn_s_setprio(2);   // waves in their product phase go first
 #endif
 #pragma unroll
@@ -1067,11 +1084,11 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             for (int t = 0; t < 16; ++t)
                 acc = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
             asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
-#if GAAST_MFMA16_SETPRIO && GAAST_MFMA16_PRIO_RAMP
+#if GAAST_MFMA16_SETPRIO && GAAST_MFMA16_PRIO_RAMP && !GAAST_SLOT_PRIO
             if (a_hi == H / 2 - 1) __builtin_amdgcn_s_setprio(3);   // the wave that is ahead stays ahead: co-resident waves drift out of phase
 #endif
         }
-#if GAAST_MFMA16_SETPRIO
+#if GAAST_MFMA16_SETPRIO && !GAAST_SLOT_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
 

@@ -496,6 +496,39 @@ def test_spinor_gemm_accumulates_into_a_shared_result_buffer():
         assert np.abs(got[i].astype(np.float64) - want).max() <= bound
 
 
+@pytest.mark.parametrize("n", [8, 10, 11, 12])
+@pytest.mark.parametrize("layout", ["strided_aligned", "strided_odd", "misaligned_base"])
+def test_spinor_gemm_row_io_forms_give_the_same_bits(n, layout):
+    """The matrix-representation kernels move rows as 16-byte pieces when base and stride allow it (k_gp_spinor12s: its FAST
+    instantiation) and component by component otherwise: the arithmetic is the same, so wrapped memory with padded, odd or
+    shifted rows must reproduce the contiguous result bit for bit and leave the padding alone."""
+    torch = pytest.importorskip("torch")
+    batch, N = 5, 1 << n
+    rng = np.random.default_rng(100 + n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    want, mask, spec = hip_eval_batch(_gp(n), [1.0] * n, rows, batch, dtype=ga.F32, flags=ga.FLAG_SPINOR_GEMM)
+    assert any("product_spinor_gemm" in l for l in spec.launches()), spec.launches()
+    pad = {"strided_aligned": 8, "strided_odd": 3, "misaligned_base": 0}[layout]   # floats of padding per row
+    shift = 1 if layout == "misaligned_base" else 0                                 # base pointer off by 4 bytes
+    keep, ins = [], []
+    for s_ in range(2):
+        flat = torch.full((batch * (N + pad) + 4,), 777.0, dtype=torch.float32, device="cuda")
+        view = flat[shift:shift + batch * (N + pad)].view(batch, N + pad)
+        view[:, :N] = torch.from_numpy(rows[s_]).cuda()
+        keep.append(flat)
+        ins.append(ga.DeviceMV.wrap_tensor(view[:, :N], n, full_grades(n)))
+    oflat = torch.full((batch * (N + pad) + 4,), -5.0, dtype=torch.float32, device="cuda")
+    oview = oflat[shift:shift + batch * (N + pad)].view(batch, N + pad)
+    out = ga.DeviceMV.wrap_tensor(oview[:, :N], n, full_grades(n))
+    spec.eval_batch(ins, batch, out=out)
+    torch.cuda.synchronize()
+    got = oview[:, :N].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32))
+    if pad:
+        assert torch.all(oview[:, N:] == -5.0)
+    assert float(oflat[0]) == -5.0 or shift == 0
+
+
 @pytest.mark.parametrize("name", ["cfg1_r3", "cfg5_sandwich", "r6_gp_full", "weird_metric_gp"])
 def test_spinor_flag_is_ignored_where_it_does_not_apply(name):
     """f64, other dimensions, degenerate metrics: the flag changes nothing."""
