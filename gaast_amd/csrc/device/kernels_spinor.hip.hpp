@@ -473,26 +473,30 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
     const double* right = static_cast<const double*>(p.right);
     double* outp = static_cast<double*>(p.out);
 
-    uint32_t lm[8], rm[8], om[8];
+    // table entries expanded once per launch (as in k_gp_spinor12s): bit 31 = negate, bit 30 = nothing to store,
+    // low bits = LDS address of the double
+    typedef __attribute__((address_space(3))) double lds_f64;
+    uint32_t lm[16], rm[16], om[16];
+    const uint32_t lds0 = uint32_t(size_t((lds_u8*)smem_raw));
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        lm[w] = uint32_t(p.left_map[tid + 512 * w]) | (uint32_t(p.left_map[tid + 512 * w + 256]) << 16);
-        rm[w] = uint32_t(p.right_map[tid + 512 * w]) | (uint32_t(p.right_map[tid + 512 * w + 256]) << 16);
-        om[w] = uint32_t(p.out_map[tid + 512 * w]) | (uint32_t(p.out_map[tid + 512 * w + 256]) << 16);
+    for (int u = 0; u < 16; ++u) {
+        const uint32_t el = p.left_map[tid + 256 * u], er = p.right_map[tid + 256 * u], eo = p.out_map[tid + 256 * u];
+        lm[u] = (el << 31) | (lds0 + ((el & 0x7ffcu) << 1));
+        rm[u] = (er << 31) | (lds0 + uint32_t(P * 8) + ((er & 0x7ffcu) << 1));
+        om[u] = (eo << 31) | ((eo & 2u) << 29) | (lds0 + ((eo & 0xfffcu) << 1));
     }
-    auto entry = [](const uint32_t (&m)[8], int u) -> uint32_t { return (u & 1) ? m[u >> 1] >> 16 : m[u >> 1]; };
     auto flip = [](double v, uint32_t sign_bit31) {     // sign flip through the high word
         return __hiloint2double(__double2hiint(v) ^ int(sign_bit31), __double2loint(v));
     };
     double va[16], vb[16];
     auto fetch = [&](int64_t item) {
-        const double* lrow = left + item * p.left_stride + tid;
-        const double* rrow = right + item * p.right_stride + tid;
+        const double* lrow = left + item * p.left_stride;    // (uniform) row base + the thread's index
+        const double* rrow = right + item * p.right_stride;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int e = tid + 256 * u;
-            va[u] = e < p.left_len ? lrow[256 * u] : 0.0;
-            vb[u] = e < p.right_len ? rrow[256 * u] : 0.0;
+            va[u] = e < p.left_len ? lrow[e] : 0.0;
+            vb[u] = e < p.right_len ? rrow[e] : 0.0;
         }
     };
     int64_t item = blockIdx.x;
@@ -502,23 +506,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
 
     for (; item < p.batch; item += gridDim.x) {
 #pragma unroll
-        for (int w = 0; w < 8; ++w) asm volatile("" : "+v"(lm[w]), "+v"(rm[w]), "+v"(om[w]));
-        // ---- 1. graded rows -> W[x][z] ----
+        for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(lm[u]), "+v"(rm[u]), "+v"(om[u]));
+        // ---- 1. graded rows -> W[x][z] ----  (no `0.0 + x`: a zero of either sign contributes the same to every sum)
         if (!p.left_full || !p.right_full) {
             for (int i = tid; i < 2 * P; i += 256) smem[i] = 0.0;
             lds_barrier<256>();
         }
-        {
-            auto put = [&](double* plane, uint32_t e, double a, int canon) {
-                if (canon) a = 0.0 + a;
-                a = flip(a, e << 31);
-                *reinterpret_cast<double*>(reinterpret_cast<char*>(plane) + ((e & 0x7ffcu) << 1)) = a;
-            };
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                put(smem, entry(lm, u), va[u], p.canon_left);
-                put(smem + P, entry(rm, u), vb[u], p.canon_right);
-            }
+        for (int u = 0; u < 16; ++u) {
+            *(lds_f64*)(lm[u] & 0x3fffffu) = flip(va[u], lm[u] & 0x80000000u);
+            *(lds_f64*)(rm[u] & 0x3fffffu) = flip(vb[u], rm[u] & 0x80000000u);
         }
         lds_barrier<256>();
 
@@ -731,16 +728,17 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
         }
         lds_barrier<256>();
         {
-            double* orow = outp + item * p.out_stride + tid;
+            double* orow = outp + item * p.out_stride;   // (uniform) row base + the thread's index
+            if (p.out_full && !p.beta) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t eo = entry(om, u);
-                double val = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(smem) + ((eo & 0xfffcu) << 1));
-                val = flip(val, eo << 31);
-                if (p.out_full && !p.beta) {
-                    orow[256 * u] = val;
-                } else if (!(eo & 2u)) {
-                    orow[256 * u] = p.beta ? orow[256 * u] + val : val;
+                for (int u = 0; u < 16; ++u)
+                    orow[tid + 256 * u] = flip(*(const lds_f64*)(om[u] & 0x3fffffu), om[u] & 0x80000000u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t eo = om[u];
+                    const double val = flip(*(const lds_f64*)(eo & 0x3fffffu), eo & 0x80000000u);
+                    if (!(eo & 0x40000000u)) orow[tid + 256 * u] = p.beta ? orow[tid + 256 * u] + val : val;
                 }
             }
         }
