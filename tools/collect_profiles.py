@@ -24,11 +24,12 @@ def main():
     rev = gaast_amd.lib().gaast_hip_version().decode()
     for d in sorted(glob.glob(os.path.join(src, "stats_*"))):
         name = os.path.basename(d)[len("stats_"):]
-        files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+        # a repeated collection merges into the same directory: the newest summary is the one bench.json belongs to
+        files = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         if not files:
             print("no kernel stats for", name)
             continue
-        rows = list(csv.reader(open(files[0], newline="")))
+        rows = list(csv.reader(open(files[-1], newline="")))
         try:
             bench = json.load(open(os.path.join(d, "bench.json")))
             note = (f"bench line of the same run: value {bench['value']:.4g} {bench['unit']}, kernel_ms {bench['roofline']['kernel_ms']:.4f}, "
@@ -36,7 +37,7 @@ def main():
         except (OSError, ValueError, KeyError):
             note = "bench line unavailable"
         with open(os.path.join(dst, f"{tag}_bench_{name}_kernel_stats.csv"), "w", newline="") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --workload {name}   ({tag}; {rev})\n")
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-latency --workload {name}   ({tag}; {rev})\n")
             f.write(f"# {note}\n")
             w = csv.writer(f)
             for r in rows[:9]:

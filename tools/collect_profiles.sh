@@ -3,7 +3,9 @@
 # --kernel-trace only), bench JSON lines.  Output under gpurun_out/prof_<tag>/; tools/collect_profiles.py files the
 # summaries under profiles/.
 #   tools/collect_profiles.sh <tag>
+#   tools/collect_profiles.sh <tag> [stats|pmc|all]     (two calls when one would exceed the GPU call's time limit)
 tag=${1:-r02}
+phase=${2:-all}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -11,8 +13,9 @@ stats() { # name, bench args...
   name=$1; shift
   d=$out/stats_$name
   rm -rf $d; mkdir -p $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency "$@" > $d/bench.json 2> $d/log.txt || echo "stats $name failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-latency "$@" > $d/bench.json 2> $d/log.txt || echo "stats $name failed"
 }
+if [ $phase != pmc ]; then
 stats r12 --workload r12
 stats r8 --workload r8
 stats cl41 --workload cl41
@@ -23,14 +26,17 @@ stats r8s --workload r8s
 stats r12d --workload r12d
 stats r8d --workload r8d
 stats gp9f32 --workload gp9f32 --no-alt
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+GAAST_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch 4096 > $out/bench_rehearsal_2ranks.json 2> $out/bench_rehearsal.err
+python3 bench.py --workload r8 > $out/bench_r8.json 2>/dev/null
+python3 bench.py --workload cl41 > $out/bench_cl41.json 2>/dev/null
+fi
+if [ $phase != stats ]; then
 for spec in "r12:k_gp_mfma32:--workload r12" "r8:k_gp_mfma16:--workload r8" "cl41:gaast_jit:--workload cl41" "cl41g1:gaast_jit:--workload cl41g1" "r12s:k_gp_spinor12s:--workload r12s"; do
   name=${spec%%:*}; rest=${spec#*:}; kern=${rest%%:*}; args=${rest#*:}
   tools/pmc_pass.sh ${tag}_$name $kern $args > $out/pmc_$name.txt 2>&1
   cp gpurun_out/pmc_${tag}_$name/summary.csv $out/pmc_${name}_summary.csv
 done
-python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-GAAST_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch 4096 > $out/bench_rehearsal_2ranks.json 2> $out/bench_rehearsal.err
-python3 bench.py --workload r8 > $out/bench_r8.json 2>/dev/null
-python3 bench.py --workload cl41 > $out/bench_cl41.json 2>/dev/null
 bash tools/sweep_dims.sh > $out/sweep_dims.txt 2>&1
+fi
 ls $out
