@@ -688,8 +688,10 @@ __device__ __forceinline__ constexpr int mfma16_k(int t) {
 // operands hold every blade in consecutive 16-byte aligned rows (p.left_contig / left_full ...: the host checks), the
 // rows of the NEXT group are fetched into registers (8 x 16 B per thread at every n) while the matrix cores work on the
 // current one; barriers between the phases wait for LDS traffic only (lds_barrier).
+// (The second launch bound, two workgroups per CU, only changes the compiler's scheduling here -- every instantiation
+//  stays under the 256 registers of two waves per SIMD anyway: n = 10 / 11 gain 7-9 % with it, n = 12 LOSES 6 %.)
 template <bool DEGENERATE, int NDIM>
-__global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs<float> p) {
+__global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_gp_mfma32p(DenseArgs<float> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
@@ -747,6 +749,11 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs
 
     // A operand of term t: s2 = mfma16_k(t), k = 2 s2 + h: +-A[a_hi][i ^ k], sign a lane constant: byte address
     // inside the item's +A / -A pair, without the step's 128 a_hi
+    // n <= 11: the A addresses are LDS ADDRESSES (the allocation's base included) and are used as such -- otherwise the
+    // compiler adds the (zero) base to every one of them in every chunk; at n = 12 that form measured slower (the register
+    // allocation it leads to: 16.06 against 15.65 ms), so there the base stays a separate term
+    constexpr bool ABS_A = NDIM <= 11;
+    const uint32_t lds0 = ABS_A ? uint32_t(size_t(lds)) : 0u;
     uint32_t ak0[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -755,7 +762,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs
         int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 5; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-        ak0[t] = item_base + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
+        ak0[t] = lds0 + item_base + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
     }
     // B side: byte offset of the lane's quad q inside the +B / -B pair = (lane constant) ^ (step constant); quads
     // 0, 1 hold the even-|s2| words (|k| parity h), quads 2, 3 the odd ones: lanes with odd |c_hi| take the odd-|k|
@@ -769,6 +776,29 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs
         if ((__builtin_popcount(uint32_t(c_hi)) & 1) && (((q >> 1) ^ h) & 1)) bq[q] ^= NEG;
     }
     const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
+    // block sign of step a_hi for this lane's column: wave-uniform part on the scalar unit, lane part = and + popcount
+    auto block_sign = [&](int a_hi) -> uint32_t {
+        uint32_t sp = uint32_t(a_hi) >> 1;
+        sp ^= sp >> 1;
+        sp ^= sp >> 2;
+        sp ^= sp >> 4;
+        sp ^= sp >> 8;
+        const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+        const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^ __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+        return uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) & 1u;
+    };
+    // n <= 12: the signs of all H steps as lane-constant bit masks, computed once per launch (a persistent workgroup
+    // reuses them for every group); n = 13 (8 words, an 8-fold unrolled loop) keeps computing them per step, and so does
+    // the DEGENERATE instantiation at n = 12 (with the masks it needs more than the 256 registers of two waves per SIMD)
+    constexpr int SIGN_WORDS = (H <= 64 || (H == 128 && !DEGENERATE)) ? H / 32 : 0;
+    uint32_t sgn[SIGN_WORDS > 0 ? SIGN_WORDS : 1] = {0};
+#pragma unroll
+    for (int w = 0; w < SIGN_WORDS; ++w) {
+        uint32_t bits = 0;
+#pragma unroll 1
+        for (int b = 0; b < 32; ++b) bits |= block_sign(32 * w + b) << b;
+        sgn[w] = bits;
+    }
 
     for (int64_t g = blockIdx.x; g < num_groups; g += gridDim.x) {
         const int64_t item0 = g * IPB;
@@ -827,40 +857,59 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256) void k_gp_mfma32p(DenseArgs
 #pragma unroll
             for (int t = 0; t < 16; ++t) ak[t] = ak0[t];
 
-            for (int a0 = 0; a0 < H; a0 += 8) {
+            // one step: the lane's B block a_hi ^ c_hi from the image of its block sign (sxs carries the sign as the NEG
+            // address bit), the 16 A words of the step at immediate offsets, 16 MFMAs
+            auto step = [&](int a_hi, int j, uint32_t sxs) {
+                uint32_t bw[16], aw[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int a_hi = a0 + j;
-                    // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
-                    uint32_t sp = uint32_t(a_hi) >> 1;
-                    sp ^= sp >> 1;
-                    sp ^= sp >> 2;
-                    sp ^= sp >> 4;
-                    sp ^= sp >> 8;
-                    const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-                    const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
-                                        __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-                    const uint32_t sbit = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) & 1u;
-                    const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
-                    const uint32_t sxs = (sbit << (n + 2)) | sx;
-                    uint32_t bw[16], aw[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t addr = b_base + (bq[q] ^ sxs);
-                        if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
-                        const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
-                        bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
-#pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
-                    asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t addr = b_base + (bq[q] ^ sxs);
+                    if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
+                    const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
+                    bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
                 }
 #pragma unroll
-                for (int t = 0; t < 16; ++t) ak[t] += 8u << 7;
+                for (int t = 0; t < 16; ++t)
+                    aw[t] = ABS_A ? *(__attribute__((address_space(3))) const uint32_t*)(ak[t] + uint32_t(j << 7))
+                                  : *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
+                asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+            };
+            if constexpr (SIGN_WORDS > 0) {
+                // block signs from the per-launch bit masks: two vector instructions per step (bit, address bit) instead
+                // of five; chunks of 16 steps (the A addresses move once per chunk)
+#pragma unroll
+                for (int w = 0; w < SIGN_WORDS; ++w) {
+                    uint32_t sw = sgn[w];
+#pragma unroll 1
+                    for (int c = 0; c < 2; ++c) {
+                        const int a0 = 32 * w + 16 * c;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int a_hi = a0 + j;
+                            // (wave-uniform: kept on the scalar unit, one v_lshl_or_b32 joins it with the lane's sign bit)
+                            uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4));
+                            asm("" : "+s"(sx));   // whole, in a scalar register: otherwise its parts are OR-ed in one by one on the vector unit
+                            step(a_hi, j, (((sw >> j) & 1u) << (n + 2)) | sx);
+                        }
+                        sw >>= 16;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) ak[t] += 16u << 7;
+                    }
+                }
+            } else {
+                for (int a0 = 0; a0 < H; a0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int a_hi = a0 + j;
+                        const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+                        step(a_hi, j, (block_sign(a_hi) << (n + 2)) | sx);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) ak[t] += 8u << 7;
+                }
             }
 
             // ---- accumulator (row = c_lo, column = this lane's c_hi) -> graded row ----
