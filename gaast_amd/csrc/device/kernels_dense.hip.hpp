@@ -870,7 +870,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                 }
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    aw[t] = ABS_A ? *(__attribute__((address_space(3))) const uint32_t*)(ak[t] + uint32_t(j << 7))
+                    aw[t] = ABS_A ? *(__attribute__((address_space(3))) const uint32_t*)size_t(ak[t] + uint32_t(j << 7))
                                   : *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
@@ -922,6 +922,136 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
             }
         }
         lds_barrier<THREADS>();   // the images are rewritten by the next group
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Matrix-core form in f64, the reference's value type (n = 8, 9, 10): v_mfma_f64_16x16x4_f64, image-pair form.
+// With lo = 4 bits the contribution of block a_hi to the 16 result columns c_hi of a tile is a 16 x 16 x 16 product,
+// four instructions of k = 4 each:
+//   lane (i, kq):  A operand of instruction s (k = 4 s + kq) = +-A[a_hi][i ^ k]        (+A / -A image by a lane constant)
+//                  B operand                                   = +-B[a_hi ^ c_hi(i)][k]  (+B / -B image by the block sign,
+//                                                                 and by the lane constant (-1)^(|c_hi| |k|))
+//   accumulator register r = row c_lo = 4 r + kq, column c_hi(i)  (the f64 instruction interleaves the row groups).
+// One wave per 16 result columns, one ITEM per workgroup (n = 8: a single wave; 8 KiB of images per item, so many
+// workgroups stay resident), persistent.  Every operand is one ds_read_b64; a B block's 16 doubles are stored at
+// k ^ (((x >> 1) & 7) << 1) inside block x, so that the 32 lanes of a read -- 16 blocks x two k -- cover 32 different
+// bank pairs; the address of a lane's word is (lane constant) ^ (step constant).  Same sums as k_gp_dense<double>: a
+// k-ordered fused multiply-add chain per result component.
+// ------------------------------------------------------------------------------------------
+typedef double double4m __attribute__((ext_vector_type(4)));
+
+template <bool DEGENERATE, int NDIM>
+__global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<double> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    lds_u8* lds = (lds_u8*)smem_raw;
+    typedef __attribute__((address_space(3))) double lds_f64;
+    constexpr int n = NDIM;                       // 8, 9, 10
+    constexpr int N = 1 << n;
+    constexpr int H = 1 << (n - 4);               // number of 16-blocks (16, 32, 64)
+    constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
+    constexpr int item_stride = 4 * N + 16;       // doubles: +A, -A, +B, -B images, 16 zeros
+    constexpr uint32_t NEG = uint32_t(N) * 8u;    // bytes from an image to its negated copy
+    const int tid = threadIdx.x;
+    if (tid < 16) smem[4 * N + tid] = 0.0;        // the B "block" of a vanishing contribution: zero for the whole launch
+
+    const int tile = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int c_hi = (tile << 4) | i;
+
+    // A operand of instruction s: byte address inside the +A / -A pair, without the step's 128 a_hi
+    uint32_t ak[4], bk[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + kq;
+        const int a_lo = i ^ k;
+        int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
+        for (int pp = 1; pp < 4; ++pp)
+            if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
+        ak[s] = (uint32_t(a_lo) << 3) + (par ? NEG : 0u);
+        // B side: (lane constant) ^ (step constant); lanes with odd |c_hi| take the odd-|k| words from the other image
+        bk[s] = (uint32_t(c_hi) << 7) | ((uint32_t((c_hi >> 1) & 7) << 4) ^ (uint32_t(k) << 3));
+        if ((__builtin_popcount(uint32_t(c_hi)) & __builtin_popcount(uint32_t(k))) & 1) bk[s] ^= NEG;
+    }
+    // block sign of every step, one bit per a_hi, and (DEGENERATE) the steps whose contribution to this column vanishes
+    uint32_t sign_bits[2] = {0, 0}, zero_bits[2] = {0, 0};
+#pragma unroll
+    for (int w = 0; w < (H + 31) / 32; ++w) {
+        uint32_t sb = 0, zb = 0;
+#pragma unroll 1
+        for (int b = 0; b < (H < 32 ? H : 32); ++b) {
+            const int a_hi = 32 * w + b;
+            uint32_t sp = uint32_t(a_hi) >> 1;
+            sp ^= sp >> 1;
+            sp ^= sp >> 2;
+            sp ^= sp >> 4;
+            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
+            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^ __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
+            sb |= ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << b;
+            if (DEGENERATE) zb |= ((uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? 1u : 0u) << b;
+        }
+        sign_bits[w] = sb;
+        zero_bits[w] = zb;
+    }
+    const uint32_t b_base = 2u * NEG, zero_block = 4u * NEG;
+    // where this lane's results go: register r = row c_lo = 4 r + kq of column c_hi
+    uint32_t ooff[4], osg[4];
+    bool ook[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int32_t w = p.out_map[(c_hi << 4) + 4 * r + kq];
+        ook[r] = w >= 0;
+        ooff[r] = uint32_t(w & 0x3fffffff) << 3;
+        osg[r] = (uint32_t(w) & 0x40000000u) << 1;
+    }
+
+    for (int64_t item = blockIdx.x; item < p.batch; item += gridDim.x) {
+        // ---- both operands into their +/- images ----
+        if (!p.left_full || !p.right_full) {
+            for (int e = tid; e < 4 * N; e += THREADS) smem[e] = 0.0;
+            lds_barrier<THREADS>();
+        }
+        stage_operands<double, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                        p.canon_left, smem, item_stride, 1, tid);
+        stage_operands<double, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                        p.right_contig, p.canon_right, smem + 2 * N, item_stride, 1, tid);
+        lds_barrier<THREADS>();
+        for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images
+            const int src = e < N ? e : e + N;
+            smem[src + N] = -smem[src];
+        }
+        lds_barrier<THREADS>();
+
+        double4m acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a_hi = 0; a_hi < H; ++a_hi) {
+            const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+            const uint32_t sxs = sx | (((sign_bits[a_hi >> 5] >> (a_hi & 31)) & 1u) ? NEG : 0u);
+            double av[4], bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uint32_t addr = b_base + (bk[s] ^ sxs);
+                if (DEGENERATE) addr = ((zero_bits[a_hi >> 5] >> (a_hi & 31)) & 1u) ? zero_block : addr;
+                bv[s] = *(const lds_f64*)(lds + addr);
+                av[s] = *(const lds_f64*)(lds + ak[s] + uint32_t(a_hi << 7));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+            asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+        }
+
+        // ---- results -> graded row: (uniform) row base + the lane's byte offsets ----
+        unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + item * p.out_stride);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (ook[r]) {
+                double* q = reinterpret_cast<double*>(orow + ooff[r]);
+                const double v = __hiloint2double(__double2hiint(acc[r]) ^ int(osg[r]), __double2loint(acc[r]));
+                *q = p.beta ? *q + v : v;
+            }
+        }
+        lds_barrier<THREADS>();   // the images are rewritten by the next item
     }
 }
 

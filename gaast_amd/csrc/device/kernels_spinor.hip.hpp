@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
-            *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
+            *(lds_u32*)size_t(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
+            *(lds_u32*)size_t(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
         }
     };
     // The loop is rotated: the rows of item i + 1 are staged at the END of item i's pass, after its result rows were
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 for (int u4 = 0; u4 < 4; ++u4) {
                     uint32_t w[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
+                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)size_t(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
                     reinterpret_cast<float4*>(orow)[tid + 256 * u4] =
                         make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
                 }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t eo = om[u];
                     const int e = 4 * tid + (u & 3) + 1024 * (u >> 2);
-                    const float val = __uint_as_float(*(const lds_u32*)(eo & 0x3fffffu) ^ (eo & 0x80000000u));
+                    const float val = __uint_as_float(*(const lds_u32*)size_t(eo & 0x3fffffu) ^ (eo & 0x80000000u));
                     if (!(eo & 0x40000000u)) orow[e] = p.beta ? orow[e] + val : val;
                 }
             }
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            *(lds_f64*)(lm[u] & 0x3fffffu) = flip(va[u], lm[u] & 0x80000000u);
-            *(lds_f64*)(rm[u] & 0x3fffffu) = flip(vb[u], rm[u] & 0x80000000u);
+            *(lds_f64*)size_t(lm[u] & 0x3fffffu) = flip(va[u], lm[u] & 0x80000000u);
+            *(lds_f64*)size_t(rm[u] & 0x3fffffu) = flip(vb[u], rm[u] & 0x80000000u);
         }
         lds_barrier<256>();
 
@@ -732,12 +732,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12d(SpinorArgs p) {
             if (p.out_full && !p.beta) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    orow[tid + 256 * u] = flip(*(const lds_f64*)(om[u] & 0x3fffffu), om[u] & 0x80000000u);
+                    orow[tid + 256 * u] = flip(*(const lds_f64*)size_t(om[u] & 0x3fffffu), om[u] & 0x80000000u);
             } else {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t eo = om[u];
-                    const double val = flip(*(const lds_f64*)(eo & 0x3fffffu), eo & 0x80000000u);
+                    const double val = flip(*(const lds_f64*)size_t(eo & 0x3fffffu), eo & 0x80000000u);
                     if (!(eo & 0x40000000u)) orow[tid + 256 * u] = p.beta ? orow[tid + 256 * u] + val : val;
                 }
             }
@@ -824,8 +824,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
         // (no `0.0 + x`: on this path a zero of either sign contributes the same to every sum)
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
-            *(lds_u32*)(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
-            *(lds_u32*)(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
+            *(lds_u32*)size_t(lm[u] & 0xffffu) = __float_as_uint(va[u]) ^ (lm[u] & 0x80000000u);
+            *(lds_u32*)size_t(rm[u] & 0xffffu) = __float_as_uint(vb[u]) ^ (rm[u] & 0x80000000u);
         }
         lds_barrier<64>();
         if (item + gridDim.x < p.batch) fetch(item + gridDim.x);
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 for (int u4 = 0; u4 < EPL / 4; ++u4) {
                     uint32_t w[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
+                    for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)size_t(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
                     reinterpret_cast<float4*>(orow)[lane + 64 * u4] =
                         make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
                 }
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                 for (int u = 0; u < EPL; ++u) {
                     const uint32_t eo = om[u];
                     const int e = 4 * lane + (u & 3) + 256 * (u >> 2);
-                    const float val = __uint_as_float(*(const lds_u32*)(eo & 0x3fffffu) ^ (eo & 0x80000000u));
+                    const float val = __uint_as_float(*(const lds_u32*)size_t(eo & 0x3fffffu) ^ (eo & 0x80000000u));
                     if (!(eo & 0x40000000u)) orow[e] = p.beta ? orow[e] + val : val;
                 }
             }

@@ -400,7 +400,7 @@ struct Lowering {
         return true;
     }
 
-    // which dense kernel (0 = none, 1 = k_gp_dense, 2 = k_gp_mfma16, 3 = k_gp_mfma32) and in which basis
+    // which dense kernel (0 = none, 1 = k_gp_dense, 2 = k_gp_mfma16, 3 = k_gp_mfma32, 4 = k_gp_mfma16d) and in which basis
     int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
         const int n = d.vec_space_dim;
@@ -418,6 +418,11 @@ struct Lowering {
         if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
         if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
         if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
+        // f64 (the reference's value type), n = 8, 9: v_mfma_f64_16x16x4_f64, one item per workgroup (at n = 10 the kernel
+        // exists and is correct but measures the same as the vector form: 22.3 M products/s either way)
+        if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 9 &&
+            dense_basis_permutation(4, false, perm))
+            return 4;
         if (dense_basis_permutation(4, true, perm)) return 1;
         return 0;
     }
@@ -561,7 +566,8 @@ struct Lowering {
             s.n_entries = nd.n_comp_muls;
             const int n = d.vec_space_dim;
             s.use_mfma = dense_kind == 3;
-            s.use_mfma16 = dense_kind == 2;
+            s.use_mfma16 = dense_kind == 2 || dense_kind == 4;
+            s.use_mfma16d = dense_kind == 4;
             s.mfma32_pairs = dense_kind == 3 && n <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
             // blade S of the program's basis <-> blade S' of the permuted basis, e_S = sign(S) e'_S' (the parity of the
             // inversions of the new positions of S's vectors taken in ascending original order)
@@ -601,6 +607,11 @@ struct Lowering {
                 const uint32_t lq = ((k & 1) << 2) | (w >> 2);
                 return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | (w & 3);
             };
+            // k_gp_mfma16d's B image (f64): word k of block x at k ^ (((x >> 1) & 7) << 1)
+            auto mfma16d_b_pos = [](uint32_t m) {
+                const uint32_t x = m >> 4, k = m & 15u;
+                return (x << 4) | (k ^ (((x >> 1) & 7u) << 1));
+            };
             auto mfma_b_pos = [](uint32_t m) {
                 const uint32_t x = m >> 5, k = m & 31;
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
@@ -622,6 +633,7 @@ struct Lowering {
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
                         const uint32_t pos = s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
                                              : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
+                                             : s.use_mfma16d ? (right ? mfma16d_b_pos(blade) : blade)
                                              : s.use_mfma16 ? (right ? mfma16_b_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();

@@ -67,7 +67,8 @@ struct Step {
     int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)
     int degenerate = 0;
     int use_mfma = 0;
-    int use_mfma16 = 0;  // k_gp_mfma16 (f32, n = 8, 9)
+    int use_mfma16 = 0;  // k_gp_mfma16 (f32, n = 8, 9) or k_gp_mfma16d
+    int use_mfma16d = 0; // k_gp_mfma16d (f64, n = 8, 9, 10): with use_mfma16
     int mfma32_pairs = 0;  // k_gp_mfma32p (image-pair form, f32, n = 10 ... 13) instead of k_gp_mfma32
     int spinor_lam_bit = -1, spinor_has_alpha = 0;  // index basis of the matrix-representation kernels: spinor_basis.hpp
     int use_spinor = 0;  // opt-in matrix-representation kernel (GAAST_FLAG_SPINOR_GEMM): log2 of the matrix size, or 0

@@ -278,6 +278,17 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 if (int st = allow_lds(s.kern[0], s.lds)) return st;
                 if (int st = allow_lds(s.kern[1], s.lds)) return st;
                 return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
+            } else {
+                s.threads = 64 << (n - 8);                     // one wave per 16 result columns, one item per workgroup
+                s.items_per_block = 1;
+                s.lds = size_t(4 * (size_t(1) << n) + 16) * sizeof(double);   // +A, -A, +B, -B images, 16 zeros
+                using KernD = void (*)(DenseArgs<double>);
+                const KernD kd = n == 8   ? (s.degenerate ? &k_gp_mfma16d<true, 8> : &k_gp_mfma16d<false, 8>)
+                                 : n == 9 ? (s.degenerate ? &k_gp_mfma16d<true, 9> : &k_gp_mfma16d<false, 9>)
+                                          : (s.degenerate ? &k_gp_mfma16d<true, 10> : &k_gp_mfma16d<false, 10>);
+                s.kern[0] = reinterpret_cast<const void*>(kd);
+                if (int st = allow_lds(s.kern[0], s.lds)) return st;
+                return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
             }
         }
         const int lpi = 1 << (n - 4);
@@ -471,7 +482,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             blocks = int64_t(g_num_cu) * s.blocks_per_cu;
             if (blocks > groups) blocks = groups;
         }
-        const bool prefetch = s.use_mfma16 && p.left_contig && p.right_contig && p.left_full && p.right_full;
+        const bool prefetch = s.use_mfma16 && s.kern[1] && p.left_contig && p.right_contig && p.left_full && p.right_full;
         hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);
         break;

@@ -98,6 +98,12 @@ static uint32_t mfma32p_b_pos(uint32_t m) {
     return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | (w & 3);
 }
 
+// k_gp_mfma16d's B image (f64; plan.cpp: mfma16d_b_pos)
+static uint32_t mfma16d_b_pos(uint32_t m) {
+    const uint32_t x = m >> 4, k = m & 15u;
+    return (x << 4) | (k ^ (((x >> 1) & 7u) << 1));
+}
+
 static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
                                              const char* expect_step) {
     gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
@@ -132,6 +138,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
     if (st->mfma32_pairs) for (uint32_t m = 0; m < N; ++m) inv_b[mfma32p_b_pos(m)] = m;
     else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
+    else if (st->use_mfma16d) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16d_b_pos(m)] = m;
     else if (st->use_mfma16) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16_b_pos(m)] = m;
     auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
         std::vector<double> img(N, 0.0);
@@ -282,7 +289,10 @@ int main() {
         dense_tables_agree_with_the_list(8, pga8, GAAST_F32, 0, "mfma16 tables n=8 null vector first", "product_dense_mfma");
         dense_tables_agree_with_the_list(8, neg8, GAAST_F32, 0, "mfma16 tables Cl(0,8)", "product_dense_mfma[gp n=8]");
         dense_tables_agree_with_the_list(8, mix8, GAAST_F32, 0, "mfma16 tables n=8 mixed", "permuted basis");
-        dense_tables_agree_with_the_list(8, neg8, GAAST_F64, 0, "vector tables Cl(0,8)", "product_dense[gp n=8]");
+        dense_tables_agree_with_the_list(8, neg8, GAAST_F64, GAAST_FLAG_NO_MFMA, "vector tables Cl(0,8)", "product_dense[gp n=8]");
+        dense_tables_agree_with_the_list(8, neg8, GAAST_F64, 0, "mfma16d tables Cl(0,8)", "product_dense_mfma[gp n=8]");
+        dense_tables_agree_with_the_list(8, mix8, GAAST_F64, 0, "mfma16d tables n=8 mixed", "permuted basis");
+        dense_tables_agree_with_the_list(9, euclid, GAAST_F64, 0, "mfma16d tables n=9 euclid", "product_dense_mfma[gp n=9]");
         const double mix10[10] = {0, -1, 1, 1, -1, 1, 0, 1, -1, 1};
         dense_tables_agree_with_the_list(10, mix10, GAAST_F32, 0, "mfma32 tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
         dense_tables_agree_with_the_list(10, euclid, GAAST_F32, 0, "mfma32 tables n=10 euclid", "product_dense_mfma[gp n=10]");

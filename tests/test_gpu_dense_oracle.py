@@ -86,12 +86,13 @@ def test_n13_eight_waves_per_item_512_thread_kernels():
 @pytest.mark.parametrize("metric", [[0.0] + [1.0] * 7, [-1.0] + [1.0] * 7, [-1.0] * 8, [1.0, 0.0, -1.0, 1.0, 0.0, -1.0, 1.0, -1.0],
                                     [-1.0, -1.0, 1.0, 0.0, -1.0, -1.0, 1.0, 1.0, -1.0]])
 def test_n8_n9_any_diagonal_metric_stays_on_the_dense_kernels(metric):
-    """PGA-style null vector first, STA-style time first, Cl(0,8), and mixtures: k_gp_mfma16 in f32 (lane-constant lo
-    signs), k_gp_dense in f64 (permutation to four like-signed lo vectors; NEGLO instantiation for Cl(0,8))"""
+    """PGA-style null vector first, STA-style time first, Cl(0,8), and mixtures: k_gp_mfma16 in f32 and k_gp_mfma16d in
+    f64 (lane-constant lo signs), k_gp_dense in both types behind GAAST_FLAG_NO_MFMA (permutation to four like-signed lo
+    vectors; NEGLO instantiation for Cl(0,8))"""
     n = len(metric)
-    variants = [(ga.F32, 0, "product_dense_mfma[")]
+    variants = [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma[")]
     if sum(m == 1.0 for m in metric) >= 4 or sum(m == -1.0 for m in metric) >= 4:
-        variants += [(ga.F64, 0, "product_dense["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense[")]
+        variants += [(ga.F64, ga.FLAG_NO_MFMA, "product_dense["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense[")]
     _check(n, metric, None, variants, batch=9, seed=80 + n)
 
 

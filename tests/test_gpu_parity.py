@@ -193,6 +193,62 @@ def test_dense_mfma16_mixed_and_degenerate_signatures_f32(n, metric):
         assert np.all(np.abs(alt[i].astype(np.float64) - want[i]) <= bound), i
 
 
+@pytest.mark.parametrize("n,metric", [(8, [1.0] * 8), (8, [1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, 1.0]), (8, [0.0, 1.0, 1.0, 1.0, 0.0, 1.0, -1.0, 1.0]),
+                                      (8, [-1.0] * 8), (9, [1.0] * 9), (9, [1.0, 1.0, -1.0, 1.0, -1.0, -1.0, 1.0, 0.0, 1.0])])
+def test_dense_mfma16d_f64_against_the_oracle(n, metric):
+    """k_gp_mfma16d (f64, v_mfma_f64_16x16x4_f64, one item per workgroup; n = 9: two waves per item): Euclidean, negative
+    and null basis vectors among lo and hi bits, a batch larger than the resident workgroups' first pass is not needed --
+    the persistent loop is exercised by 37 items on however many workgroups fit -- and the vector-FMA kernel
+    (GAAST_FLAG_NO_MFMA) as a second opinion where it applies"""
+    batch = 37
+    rng = np.random.default_rng(170 + n)
+    rows = {0: rows_of(n, full_grades(n), batch, rng), 1: rows_of(n, full_grades(n), batch, rng)}
+    want, _ = oracle_eval_batch(_gp(n), metric, rows, batch)
+    got, _, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F64)
+    assert any(l.startswith("product_dense_mfma[") for l in spec.launches()), spec.launches()
+    for i in range(batch):
+        bound = _dense_bound(n, np.abs(metric), rows[0][i], rows[1][i], 2.0 ** -52)
+        assert np.all(np.abs(got[i] - want[i]) <= bound), i
+    if sum(m == 1.0 for m in metric) >= 4 or sum(m == -1.0 for m in metric) >= 4:
+        alt, _, spec2 = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F64, flags=ga.FLAG_NO_MFMA)
+        assert any(l.startswith("product_dense[") for l in spec2.launches()), spec2.launches()
+        for i in range(batch):
+            bound = _dense_bound(n, np.abs(metric), rows[0][i], rows[1][i], 2.0 ** -52)
+            assert np.all(np.abs(alt[i] - want[i]) <= bound), i
+
+
+def test_dense_mfma16d_f64_basis_blades_and_partial_grades():
+    """one-hot operands are reproduced exactly (every product of basis blades, sign included), and operands that hold only
+    some grades / a projected result go through the general staging and the result map"""
+    n = 8
+    from helpers import blades_in_row_order
+    blades = blades_in_row_order(n, full_grades(n))
+    N = 1 << n
+    rng = np.random.default_rng(8)
+    batch = 64
+    ia, ib = rng.integers(0, N, batch), rng.integers(0, N, batch)
+    A = np.zeros((batch, N)); B = np.zeros((batch, N))
+    A[np.arange(batch), ia] = 1.0
+    B[np.arange(batch), ib] = -2.0
+    rows = {0: A, 1: B}
+    metric = [1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 1.0, -1.0]
+    want, _ = oracle_eval_batch(_gp(n), metric, rows, batch)
+    got, _, spec = hip_eval_batch(_gp(n), metric, rows, batch, dtype=ga.F64)
+    assert any(l.startswith("product_dense_mfma[") for l in spec.launches()), spec.launches()
+    assert np.array_equal(got, want)
+    # partial grades: even x (odd + grade 8) -> grades 1, 3 projected
+    lg, rg = [0, 2, 4, 6, 8], [1, 3, 5, 7, 8]
+    build = lambda Bk: (Bk.input(0, lg, n) * Bk.input(1, rg, n)).gselect([1, 3, 5])
+    rows = {0: rows_of(n, lg, 5, rng), 1: rows_of(n, rg, 5, rng)}
+    want, wmask = oracle_eval_batch(build, n, rows, 5)
+    got, mask, spec = hip_eval_batch(build, n, rows, 5, dtype=ga.F64)
+    assert mask == wmask
+    if any("product_dense" in l for l in spec.launches()):
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    else:
+        assert np.array_equal(got, want)
+
+
 def test_dense_gp_partial_grades_and_projection():
     """even * full -> grades {1,3,5}: absent operand grades are zeros, unwanted outputs dropped."""
     n = 7
