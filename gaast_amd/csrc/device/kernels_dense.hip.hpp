@@ -941,13 +941,16 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
 // ------------------------------------------------------------------------------------------
 typedef double double4m __attribute__((ext_vector_type(4)));
 
-template <bool DEGENERATE, int NDIM>
+// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): thread t moves the 16-byte
+// pieces t and t + THREADS of every row, its map words (image address, sign) stay in registers, and the rows of the NEXT
+// item are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging.
+template <bool DEGENERATE, int NDIM, bool FAST>
 __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<double> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
     typedef __attribute__((address_space(3))) double lds_f64;
-    constexpr int n = NDIM;                       // 8, 9, 10
+    constexpr int n = NDIM;                       // 8 ... 12
     constexpr int N = 1 << n;
     constexpr int H = 1 << (n - 4);               // number of 16-blocks (16, 32, 64)
     constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
@@ -975,12 +978,13 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
         if ((__builtin_popcount(uint32_t(c_hi)) & __builtin_popcount(uint32_t(k))) & 1) bk[s] ^= NEG;
     }
     // block sign of every step, one bit per a_hi, and (DEGENERATE) the steps whose contribution to this column vanishes
-    uint32_t sign_bits[2] = {0, 0}, zero_bits[2] = {0, 0};
+    constexpr int SW = (H + 31) / 32, SB = H < 32 ? H : 32;   // words of step bits, steps per word
+    uint32_t sign_bits[SW], zero_bits[SW];
 #pragma unroll
-    for (int w = 0; w < (H + 31) / 32; ++w) {
+    for (int w = 0; w < SW; ++w) {
         uint32_t sb = 0, zb = 0;
 #pragma unroll 1
-        for (int b = 0; b < (H < 32 ? H : 32); ++b) {
+        for (int b = 0; b < SB; ++b) {
             const int a_hi = 32 * w + b;
             uint32_t sp = uint32_t(a_hi) >> 1;
             sp ^= sp >> 1;
@@ -1006,8 +1010,59 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
         osg[r] = (uint32_t(w) & 0x40000000u) << 1;
     }
 
+    // FAST: byte address inside the +A / +B image and negate bit of the thread's 2 x 2 components per row
+    static_assert(N / 2 == 2 * THREADS, "two 16-byte pieces of each row per thread");
+    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    double2 pf_l[2], pf_r[2];
+    auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's pieces
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            pf_l[m] = reinterpret_cast<const double2*>(p.left + item * p.left_stride)[tid + m * THREADS];
+            pf_r[m] = reinterpret_cast<const double2*>(p.right + item * p.right_stride)[tid + m * THREADS];
+        }
+    };
+    if (FAST) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const uint2 ml = reinterpret_cast<const uint2*>(p.left_map)[tid + m * THREADS];
+            const uint2 mr = reinterpret_cast<const uint2*>(p.right_map)[tid + m * THREADS];
+            const uint32_t mls[2] = {ml.x, ml.y}, mrs[2] = {mr.x, mr.y};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                wa[2 * m + c] = ((mls[c] >> 16) & 0x7fffu) << 3;
+                wb[2 * m + c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(2 * N)) << 3;
+                sa[2 * m + c] = mls[c] & 0x80000000u;
+                sb[2 * m + c] = mrs[c] & 0x80000000u;
+            }
+        }
+        if (int64_t(blockIdx.x) < p.batch) fetch(blockIdx.x);
+    }
+    auto flip_hi = [](double v, uint32_t sign_bit31) { return __hiloint2double(__double2hiint(v) ^ int(sign_bit31), __double2loint(v)); };
+
     for (int64_t item = blockIdx.x; item < p.batch; item += gridDim.x) {
         // ---- both operands into their +/- images ----
+        if (FAST) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const double xl[2] = {pf_l[m].x, pf_l[m].y}, xr[2] = {pf_r[m].x, pf_r[m].y};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double yl = xl[c], yr = xr[c];
+#if !GAAST_DENSE_NO_CANON
+                    if (p.canon_left) yl = 0.0 + yl;    // the reference's zero-init + add_grades_from copy: 0.0 + x
+                    if (p.canon_right) yr = 0.0 + yr;
+#endif
+                    yl = flip_hi(yl, sa[2 * m + c]);
+                    yr = flip_hi(yr, sb[2 * m + c]);
+                    *(lds_f64*)(lds + wa[2 * m + c]) = yl;
+                    *(lds_f64*)(lds + wa[2 * m + c] + NEG) = -yl;
+                    *(lds_f64*)(lds + wb[2 * m + c]) = yr;
+                    *(lds_f64*)(lds + wb[2 * m + c] + NEG) = -yr;
+                }
+            }
+            lds_barrier<THREADS>();
+            if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // in flight during the products below
+        } else {
         if (!p.left_full || !p.right_full) {
             for (int e = tid; e < 4 * N; e += THREADS) smem[e] = 0.0;
             lds_barrier<THREADS>();
@@ -1022,23 +1077,58 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
             smem[src + N] = -smem[src];
         }
         lds_barrier<THREADS>();
+        }
 
         double4m acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a_hi = 0; a_hi < H; ++a_hi) {
-            const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
-            const uint32_t sxs = sx | (((sign_bits[a_hi >> 5] >> (a_hi & 31)) & 1u) ? NEG : 0u);
+        // one step: the lane's four B words and four A words (one ds_read_b64 each), four MFMAs
+        auto step = [&](int a_hi, uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff) {
             double av[4], bv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint32_t addr = b_base + (bk[s] ^ sxs);
-                if (DEGENERATE) addr = ((zero_bits[a_hi >> 5] >> (a_hi & 31)) & 1u) ? zero_block : addr;
+                if (DEGENERATE) addr = zero ? zero_block : addr;
                 bv[s] = *(const lds_f64*)(lds + addr);
-                av[s] = *(const lds_f64*)(lds + ak[s] + uint32_t(a_hi << 7));
+                av[s] = *(const lds_f64*)(lds + abase[s] + uint32_t(joff << 7));
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
             asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
+        };
+        if constexpr (SW == 1) {
+            // n = 8, 9: all steps unrolled -- every address of a step is a lane constant the compiler keeps across items
+#pragma unroll
+            for (int a_hi = 0; a_hi < H; ++a_hi) {
+                const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+                step(a_hi, sx | (((sign_bits[0] >> a_hi) & 1u) ? NEG : 0u), (zero_bits[0] >> a_hi) & 1u, ak, a_hi);
+            }
+        } else {
+            // n >= 10: 32 steps per pass of a rolled outer loop; the step bits of the current pass sit in word 0 and the
+            // words rotate once per pass (register indices stay compile-time, the body stays 32 steps long whatever n is)
+            uint32_t sw[SW], zw[SW], aw_base[4];
+#pragma unroll
+            for (int w = 0; w < SW; ++w) {
+                sw[w] = sign_bits[w];
+                zw[w] = zero_bits[w];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) aw_base[s] = ak[s];
+#pragma unroll 1
+            for (int w = 0; w < SW; ++w) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int a_hi = 32 * w + j;
+                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4));
+                    asm("" : "+s"(sx));   // whole, in a scalar register
+                    step(a_hi, sx | (((sw[0] >> j) & 1u) << (n + 3)), (zw[0] >> j) & 1u, aw_base, j);   // NEG = 2^(n + 3) bytes
+                }
+#pragma unroll
+                for (int q = 0; q + 1 < SW; ++q) {
+                    sw[q] = sw[q + 1];
+                    zw[q] = zw[q + 1];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) aw_base[s] += 32u << 7;
+            }
         }
 
         // ---- results -> graded row: (uniform) row base + the lane's byte offsets ----

@@ -420,7 +420,7 @@ struct Lowering {
         if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
         // f64 (the reference's value type), n = 8, 9: v_mfma_f64_16x16x4_f64, one item per workgroup (at n = 10 the kernel
         // exists and is correct but measures the same as the vector form: 22.3 M products/s either way)
-        if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 9 &&
+        if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 12 &&
             dense_basis_permutation(4, false, perm))
             return 4;
         if (dense_basis_permutation(4, true, perm)) return 1;

@@ -296,6 +296,7 @@ int main() {
         const double mix10[10] = {0, -1, 1, 1, -1, 1, 0, 1, -1, 1};
         dense_tables_agree_with_the_list(10, mix10, GAAST_F32, 0, "mfma32 tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
         dense_tables_agree_with_the_list(10, euclid, GAAST_F32, 0, "mfma32 tables n=10 euclid", "product_dense_mfma[gp n=10]");
+        dense_tables_agree_with_the_list(10, mix10, GAAST_F64, 0, "mfma16d tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
     }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {

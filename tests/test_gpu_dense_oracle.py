@@ -45,36 +45,37 @@ def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
         assert np.abs(want).max() > 1.0     # a real product, not zeros
 
 
-def test_n10_f64_vector_kernel():
-    """k_gp_dense<double, false, 256>: 64 lanes per item, four items per workgroup"""
-    _check(10, [1.0] * 10, None, [(ga.F64, 0, "product_dense[")], batch=5, seed=10)
+def test_n10_f64_matrix_core_and_vector_kernels():
+    """k_gp_mfma16d<false, 10> (four waves per item) and, behind GAAST_FLAG_NO_MFMA, k_gp_dense<double, false, 256>: 64 lanes
+    per item, four items per workgroup"""
+    _check(10, [1.0] * 10, None, [(ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=5, seed=10)
 
 
 def test_n11_f32_two_waves_per_item_and_f64():
     """k_gp_mfma32<false, 256> with 2 waves per item (2 items per workgroup, ragged last workgroup); k_gp_dense f32 / f64"""
     _check(11, [1.0] * 11, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
-                                  (ga.F64, 0, "product_dense[")], batch=3, seed=11)
+                                  (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=3, seed=11)
 
 
 def test_n12_f32_and_f64_against_the_oracle():
     """BASELINE configs[2] kernel (k_gp_mfma32<false, 256>, 4 waves per item) and the f64 workload r12d
     (k_gp_dense<double, false, 256>), two items, all 4096 components, against the reference's 16.7 M-entry table"""
     _check(12, [1.0] * 12, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
-                                  (ga.F64, 0, "product_dense[")], batch=2, seed=12)
+                                  (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=2, seed=12)
 
 
 def test_n12_mixed_signature_negative_vectors_among_lo_and_hi_bits():
     """-1 at positions 1, 3 (lo bits of every kernel), 7, 10 (hi bits): the matrix-core kernel takes the lo signs as lane
     constants; the vector kernel needs four like-signed lo vectors and gets them by a basis permutation"""
     metric = [1.0, -1.0, 1.0, -1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0]
-    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense[")], batch=1, seed=13)
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=1, seed=13)
 
 
 def test_n12_degenerate_metric_null_vector_first():
     """the reference's PGA habit of putting the null vector first (eval.rs:132), at n = 12, plus a -1 and a second null
     vector: the basis permutation moves the null vectors to the hi bits"""
     metric = [0.0, 1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0]
-    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense[")], batch=1, seed=14)
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=1, seed=14)
 
 
 def test_n13_eight_waves_per_item_512_thread_kernels():
