@@ -941,29 +941,56 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
 // ------------------------------------------------------------------------------------------
 typedef double double4m __attribute__((ext_vector_type(4)));
 
-// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): thread t moves the 16-byte
-// pieces t and t + THREADS of every row, its map words (image address, sign) stay in registers, and the rows of the NEXT
-// item are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging.
-template <bool DEGENERATE, int NDIM, bool FAST>
-__global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<double> p) {
+// the two 16x16x4 instructions behind one name; their accumulator layouts differ: register r of lane group kq holds row
+// 4 kq + r in f32 and row 4 r + kq in f64 (found with one-hot operands)
+template <typename T>
+struct Mfma16x4;
+template <>
+struct Mfma16x4<double> {
+    typedef double4m acc_t;
+    static constexpr int SHIFT = 3;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int r) { return 4 * r + kq; }
+    static __device__ __forceinline__ double flip(double v, uint32_t bit31) { return __hiloint2double(__double2hiint(v) ^ int(bit31), __double2loint(v)); }
+};
+template <>
+struct Mfma16x4<float> {
+    typedef float4v acc_t;
+    static constexpr int SHIFT = 2;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+    static __device__ __forceinline__ float flip(float v, uint32_t bit31) { return __uint_as_float(__float_as_uint(v) ^ bit31); }
+};
+
+// k_gp_mfma16x4<T, ...>: T = double is the kernel the documents call k_gp_mfma16d; T = float is the same kernel on
+// v_mfma_f32_16x16x4_f32 (one item per workgroup instead of k_gp_mfma16's four items per instruction).
+// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): a thread moves its 16-byte
+// pieces of every row (f64: two per row, f32: one), their map words (image address, sign) stay in registers, and the rows
+// of the NEXT item are fetched into registers while the matrix cores work on the current one.  Otherwise: the general
+// staging.
+template <typename T, bool DEGENERATE, int NDIM, bool FAST>
+__global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* smem = reinterpret_cast<double*>(smem_raw);
+    T* smem = reinterpret_cast<T*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
-    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) T lds_t;
+    typedef Mfma16x4<T> MM;
+    constexpr int ES = MM::SHIFT;                 // log2 of the element size
     constexpr int n = NDIM;                       // 8 ... 12
     constexpr int N = 1 << n;
-    constexpr int H = 1 << (n - 4);               // number of 16-blocks (16, 32, 64)
+    constexpr int H = 1 << (n - 4);               // number of 16-blocks
     constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
-    constexpr int item_stride = 4 * N + 16;       // doubles: +A, -A, +B, -B images, 16 zeros
-    constexpr uint32_t NEG = uint32_t(N) * 8u;    // bytes from an image to its negated copy
+    constexpr int item_stride = 4 * N + 16;       // elements: +A, -A, +B, -B images, 16 zeros
+    constexpr uint32_t NEG = uint32_t(N) << ES;   // bytes from an image to its negated copy
+    constexpr int BS = 4 + ES;                    // log2 of a 16-block's bytes
     const int tid = threadIdx.x;
-    if (tid < 16) smem[4 * N + tid] = 0.0;        // the B "block" of a vanishing contribution: zero for the whole launch
+    if (tid < 16) smem[4 * N + tid] = T(0);       // the B "block" of a vanishing contribution: zero for the whole launch
 
     const int tile = tid >> 6, lane = tid & 63;
     const int i = lane & 15, kq = lane >> 4;
     const int c_hi = (tile << 4) | i;
 
-    // A operand of instruction s: byte address inside the +A / -A pair, without the step's 128 a_hi
+    // A operand of instruction s: byte address inside the +A / -A pair, without the step's block offset
     uint32_t ak[4], bk[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -972,9 +999,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
         int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-        ak[s] = (uint32_t(a_lo) << 3) + (par ? NEG : 0u);
+        ak[s] = (uint32_t(a_lo) << ES) + (par ? NEG : 0u);
         // B side: (lane constant) ^ (step constant); lanes with odd |c_hi| take the odd-|k| words from the other image
-        bk[s] = (uint32_t(c_hi) << 7) | ((uint32_t((c_hi >> 1) & 7) << 4) ^ (uint32_t(k) << 3));
+        bk[s] = (uint32_t(c_hi) << BS) | ((uint32_t((c_hi >> 1) & 7) << (1 + ES)) ^ (uint32_t(k) << ES));
         if ((__builtin_popcount(uint32_t(c_hi)) & __builtin_popcount(uint32_t(k))) & 1) bk[s] ^= NEG;
     }
     // block sign of every step, one bit per a_hi, and (DEGENERATE) the steps whose contribution to this column vanishes
@@ -999,106 +1026,101 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
         zero_bits[w] = zb;
     }
     const uint32_t b_base = 2u * NEG, zero_block = 4u * NEG;
-    // where this lane's results go: register r = row c_lo = 4 r + kq of column c_hi
+    // where this lane's results go: register r = row c_lo = MM::row(kq, r) of column c_hi
     uint32_t ooff[4], osg[4];
     bool ook[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int32_t w = p.out_map[(c_hi << 4) + 4 * r + kq];
+        const int32_t w = p.out_map[(c_hi << 4) + MM::row(kq, r)];
         ook[r] = w >= 0;
-        ooff[r] = uint32_t(w & 0x3fffffff) << 3;
+        ooff[r] = uint32_t(w & 0x3fffffff) << ES;
         osg[r] = (uint32_t(w) & 0x40000000u) << 1;
     }
 
-    // FAST: byte address inside the +A / +B image and negate bit of the thread's 2 x 2 components per row
-    static_assert(N / 2 == 2 * THREADS, "two 16-byte pieces of each row per thread");
+    // FAST: byte address inside the +A / +B image and negate bit of the thread's four components per row
+    constexpr int CPP = 16 >> ES;                 // components per 16-byte piece
+    constexpr int PPT = 4 / CPP;                  // pieces per thread and row
+    static_assert((N / CPP) == PPT * THREADS, "four components of each row per thread");
     uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    double2 pf_l[2], pf_r[2];
+    T pf_l[4], pf_r[4];
     auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's pieces
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            pf_l[m] = reinterpret_cast<const double2*>(p.left + item * p.left_stride)[tid + m * THREADS];
-            pf_r[m] = reinterpret_cast<const double2*>(p.right + item * p.right_stride)[tid + m * THREADS];
+        for (int m = 0; m < PPT; ++m) {
+            const uint4 xl = reinterpret_cast<const uint4*>(p.left + item * p.left_stride)[tid + m * THREADS];
+            const uint4 xr = reinterpret_cast<const uint4*>(p.right + item * p.right_stride)[tid + m * THREADS];
+            __builtin_memcpy(&pf_l[m * CPP], &xl, 16);
+            __builtin_memcpy(&pf_r[m * CPP], &xr, 16);
         }
     };
     if (FAST) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const uint2 ml = reinterpret_cast<const uint2*>(p.left_map)[tid + m * THREADS];
-            const uint2 mr = reinterpret_cast<const uint2*>(p.right_map)[tid + m * THREADS];
-            const uint32_t mls[2] = {ml.x, ml.y}, mrs[2] = {mr.x, mr.y};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                wa[2 * m + c] = ((mls[c] >> 16) & 0x7fffu) << 3;
-                wb[2 * m + c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(2 * N)) << 3;
-                sa[2 * m + c] = mls[c] & 0x80000000u;
-                sb[2 * m + c] = mrs[c] & 0x80000000u;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int idx = ((e / CPP) * THREADS + tid) * CPP + (e % CPP);   // component of the row
+            const uint32_t ml = p.left_map[idx], mr = p.right_map[idx];
+            wa[e] = ((ml >> 16) & 0x7fffu) << ES;
+            wb[e] = (((mr >> 16) & 0x7fffu) + uint32_t(2 * N)) << ES;
+            sa[e] = ml & 0x80000000u;
+            sb[e] = mr & 0x80000000u;
         }
         if (int64_t(blockIdx.x) < p.batch) fetch(blockIdx.x);
     }
-    auto flip_hi = [](double v, uint32_t sign_bit31) { return __hiloint2double(__double2hiint(v) ^ int(sign_bit31), __double2loint(v)); };
 
     for (int64_t item = blockIdx.x; item < p.batch; item += gridDim.x) {
         // ---- both operands into their +/- images ----
         if (FAST) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const double xl[2] = {pf_l[m].x, pf_l[m].y}, xr[2] = {pf_r[m].x, pf_r[m].y};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double yl = xl[c], yr = xr[c];
+            for (int e = 0; e < 4; ++e) {
+                T yl = pf_l[e], yr = pf_r[e];
 #if !GAAST_DENSE_NO_CANON
-                    if (p.canon_left) yl = 0.0 + yl;    // the reference's zero-init + add_grades_from copy: 0.0 + x
-                    if (p.canon_right) yr = 0.0 + yr;
+                if (p.canon_left) yl = T(0) + yl;    // the reference's zero-init + add_grades_from copy: 0.0 + x
+                if (p.canon_right) yr = T(0) + yr;
 #endif
-                    yl = flip_hi(yl, sa[2 * m + c]);
-                    yr = flip_hi(yr, sb[2 * m + c]);
-                    *(lds_f64*)(lds + wa[2 * m + c]) = yl;
-                    *(lds_f64*)(lds + wa[2 * m + c] + NEG) = -yl;
-                    *(lds_f64*)(lds + wb[2 * m + c]) = yr;
-                    *(lds_f64*)(lds + wb[2 * m + c] + NEG) = -yr;
-                }
+                yl = MM::flip(yl, sa[e]);
+                yr = MM::flip(yr, sb[e]);
+                *(lds_t*)(lds + wa[e]) = yl;
+                *(lds_t*)(lds + wa[e] + NEG) = -yl;
+                *(lds_t*)(lds + wb[e]) = yr;
+                *(lds_t*)(lds + wb[e] + NEG) = -yr;
             }
             lds_barrier<THREADS>();
             if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // in flight during the products below
         } else {
-        if (!p.left_full || !p.right_full) {
-            for (int e = tid; e < 4 * N; e += THREADS) smem[e] = 0.0;
+            if (!p.left_full || !p.right_full) {
+                for (int e = tid; e < 4 * N; e += THREADS) smem[e] = T(0);
+                lds_barrier<THREADS>();
+            }
+            stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                       p.canon_left, smem, item_stride, 1, tid);
+            stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem + 2 * N, item_stride, 1, tid);
+            lds_barrier<THREADS>();
+            for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images
+                const int src = e < N ? e : e + N;
+                smem[src + N] = -smem[src];
+            }
             lds_barrier<THREADS>();
         }
-        stage_operands<double, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                        p.canon_left, smem, item_stride, 1, tid);
-        stage_operands<double, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                        p.right_contig, p.canon_right, smem + 2 * N, item_stride, 1, tid);
-        lds_barrier<THREADS>();
-        for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images
-            const int src = e < N ? e : e + N;
-            smem[src + N] = -smem[src];
-        }
-        lds_barrier<THREADS>();
-        }
 
-        double4m acc = {0.0, 0.0, 0.0, 0.0};
-        // one step: the lane's four B words and four A words (one ds_read_b64 each), four MFMAs
+        typename MM::acc_t acc = {T(0), T(0), T(0), T(0)};
+        // one step: the lane's four B words and four A words (one LDS read each), four MFMAs
         auto step = [&](int a_hi, uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff) {
-            double av[4], bv[4];
+            T av[4], bv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 uint32_t addr = b_base + (bk[s] ^ sxs);
                 if (DEGENERATE) addr = zero ? zero_block : addr;
-                bv[s] = *(const lds_f64*)(lds + addr);
-                av[s] = *(const lds_f64*)(lds + abase[s] + uint32_t(joff << 7));
+                bv[s] = *(const lds_t*)(lds + addr);
+                av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) acc = MM::mma(av[s], bv[s], acc);
             asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
         };
         if constexpr (SW == 1) {
             // n = 8, 9: all steps unrolled -- every address of a step is a lane constant the compiler keeps across items
 #pragma unroll
             for (int a_hi = 0; a_hi < H; ++a_hi) {
-                const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
+                const uint32_t sx = (uint32_t(a_hi) << BS) | (uint32_t((a_hi >> 1) & 7) << (1 + ES));
                 step(a_hi, sx | (((sign_bits[0] >> a_hi) & 1u) ? NEG : 0u), (zero_bits[0] >> a_hi) & 1u, ak, a_hi);
             }
         } else {
@@ -1117,9 +1139,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
                     const int a_hi = 32 * w + j;
-                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4));
+                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << BS) | (uint32_t((a_hi >> 1) & 7) << (1 + ES)));
                     asm("" : "+s"(sx));   // whole, in a scalar register
-                    step(a_hi, sx | (((sw[0] >> j) & 1u) << (n + 3)), (zw[0] >> j) & 1u, aw_base, j);   // NEG = 2^(n + 3) bytes
+                    step(a_hi, sx | (((sw[0] >> j) & 1u) << (n + ES)), (zw[0] >> j) & 1u, aw_base, j);   // NEG = 2^(n + ES) bytes
                 }
 #pragma unroll
                 for (int q = 0; q + 1 < SW; ++q) {
@@ -1127,7 +1149,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
                     zw[q] = zw[q + 1];
                 }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) aw_base[s] += 32u << 7;
+                for (int s = 0; s < 4; ++s) aw_base[s] += 32u << BS;
             }
         }
 
@@ -1136,8 +1158,8 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16d(DenseArgs<doubl
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (ook[r]) {
-                double* q = reinterpret_cast<double*>(orow + ooff[r]);
-                const double v = __hiloint2double(__double2hiint(acc[r]) ^ int(osg[r]), __double2loint(acc[r]));
+                T* q = reinterpret_cast<T*>(orow + ooff[r]);
+                const T v = MM::flip(acc[r], osg[r]);
                 *q = p.beta ? *q + v : v;
             }
         }

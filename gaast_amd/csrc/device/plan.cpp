@@ -22,6 +22,12 @@
 #include <map>
 #include <stdexcept>
 
+// f32 at n = 8, 9: 1 = k_gp_mfma16x4<float> (one item per workgroup; measured 8-10 % faster), 0 = k_gp_mfma16 (four items per
+// v_mfma_f32_16x16x1_4b_f32); a build-time switch for A/B runs (make KFLAGS=-DGAAST_F32_MFMA16X4=0 OUTDIR=...)
+#ifndef GAAST_F32_MFMA16X4
+#define GAAST_F32_MFMA16X4 1
+#endif
+
 namespace gaast {
 namespace {
 
@@ -417,6 +423,9 @@ struct Lowering {
         // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (four items per wave)
         if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
         if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
+#if GAAST_F32_MFMA16X4
+        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 4;
+#endif
         if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
         // f64 (the reference's value type), n = 8, 9: v_mfma_f64_16x16x4_f64, one item per workgroup (at n = 10 the kernel
         // exists and is correct but measures the same as the vector form: 22.3 M products/s either way)

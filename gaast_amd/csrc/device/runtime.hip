@@ -261,6 +261,31 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 return allow_lds(s.kern[0], s.lds);
             }
         }
+        if (s.use_mfma16 && s.use_mfma16d) {
+            // k_gp_mfma16x4<T>: one wave per 16 result columns, one item per workgroup (f64: n = 8 ... 12; f32: build switch)
+            s.threads = 64 << (n - 8);
+            s.items_per_block = 1;
+            s.lds = size_t(4 * (size_t(1) << n) + 16) * sizeof(T);   // +A, -A, +B, -B images, 16 zeros
+            if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
+            using KernD = void (*)(DenseArgs<T>);
+            // [0]: general staging; [1]: register prefetch (full, contiguous, 16-byte aligned rows at launch)
+            auto pick = [&](auto fast_tag) -> KernD {
+                constexpr bool F = decltype(fast_tag)::value;
+                switch (n) {
+                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, F> : &k_gp_mfma16x4<T, false, 8, F>;
+                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, F> : &k_gp_mfma16x4<T, false, 9, F>;
+                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, F> : &k_gp_mfma16x4<T, false, 10, F>;
+                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, F> : &k_gp_mfma16x4<T, false, 11, F>;
+                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
+                }
+            };
+            const KernD kd = pick(std::false_type{}), kf = pick(std::true_type{});
+            s.kern[0] = reinterpret_cast<const void*>(kd);
+            s.kern[1] = reinterpret_cast<const void*>(kf);
+            if (int st = allow_lds(s.kern[0], s.lds)) return st;
+            if (int st = allow_lds(s.kern[1], s.lds)) return st;
+            return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
+        }
         if (s.use_mfma16) {
             if constexpr (!is_f64) {
                 s.threads = 64 << (n - 8);                     // one wave per 16 result columns of a group of four items
@@ -275,29 +300,6 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                                           : (s.degenerate ? &k_gp_mfma16<true, 9, true> : &k_gp_mfma16<false, 9, true>);
                 s.kern[0] = reinterpret_cast<const void*>(general);
                 s.kern[1] = reinterpret_cast<const void*>(fast);
-                if (int st = allow_lds(s.kern[0], s.lds)) return st;
-                if (int st = allow_lds(s.kern[1], s.lds)) return st;
-                return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
-            } else {
-                s.threads = 64 << (n - 8);                     // one wave per 16 result columns, one item per workgroup
-                s.items_per_block = 1;
-                s.lds = size_t(4 * (size_t(1) << n) + 16) * sizeof(double);   // +A, -A, +B, -B images, 16 zeros
-                if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
-                using KernD = void (*)(DenseArgs<double>);
-                // [0]: general staging; [1]: register prefetch (full, contiguous, 16-byte aligned rows at launch)
-                auto pick = [&](auto fast_tag) -> KernD {
-                    constexpr bool F = decltype(fast_tag)::value;
-                    switch (n) {
-                    case 8: return s.degenerate ? &k_gp_mfma16d<true, 8, F> : &k_gp_mfma16d<false, 8, F>;
-                    case 9: return s.degenerate ? &k_gp_mfma16d<true, 9, F> : &k_gp_mfma16d<false, 9, F>;
-                    case 10: return s.degenerate ? &k_gp_mfma16d<true, 10, F> : &k_gp_mfma16d<false, 10, F>;
-                    case 11: return s.degenerate ? &k_gp_mfma16d<true, 11, F> : &k_gp_mfma16d<false, 11, F>;
-                    default: return s.degenerate ? &k_gp_mfma16d<true, 12, F> : &k_gp_mfma16d<false, 12, F>;
-                    }
-                };
-                const KernD kd = pick(std::false_type{}), kf = pick(std::true_type{});
-                s.kern[0] = reinterpret_cast<const void*>(kd);
-                s.kern[1] = reinterpret_cast<const void*>(kf);
                 if (int st = allow_lds(s.kern[0], s.lds)) return st;
                 if (int st = allow_lds(s.kern[1], s.lds)) return st;
                 return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
