@@ -340,6 +340,26 @@ def test_exact_order_sum_of_dense_products_accumulates_bit_exact():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,dtype", [(8, ga.F32), (8, ga.F64), (9, ga.F64), (10, ga.F32), (10, ga.F64)])
+def test_sum_of_dense_products_accumulates_on_the_matrix_core_kernels(n, dtype):
+    """a*b + c*d on the default (re-ordered) path: the second product adds into the buffer the first one wrote (beta = 1) --
+    the read-modify-write result path of k_gp_mfma16x4<float / double> and k_gp_mfma32p; one shared operand (batch-1 row)"""
+    batch = 7
+    fg = full_grades(n)
+    rng = np.random.default_rng(190 + n)
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    build = lambda B: B.input(0, fg, n) * B.input(1, fg, n) + B.input(2, fg, n) * B.input(3, fg, n)
+    rows = {s: rows_of(n, fg, batch if s != 2 else 1, rng, npdt) for s in range(4)}
+    want, _ = oracle_eval_batch(build, n, rows, batch)
+    got, _, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+    assert sum(l.startswith("product_dense_mfma[") for l in spec.launches()) == 2, spec.launches()
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+    for i in range(batch):
+        bound = (_dense_bound(n, [1.0] * n, rows[0][i], rows[1][i], eps) +
+                 _dense_bound(n, [1.0] * n, rows[2][0], rows[3][i], eps)) * 1.5
+        assert np.all(np.abs(got[i].astype(np.float64) - want[i]) <= bound), i
+
+
 def test_exact_order_degenerate_metric_keeps_the_coefficient_list():
     """a zero in the metric makes 0.0 coefficients (entries the reference still executes): k_product_csr"""
     n, batch = 7, 6
