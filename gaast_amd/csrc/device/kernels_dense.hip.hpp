@@ -951,6 +951,8 @@ struct Mfma16x4<double> {
     static constexpr int SHIFT = 3;
     static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int kq, int r) { return 4 * r + kq; }
+    static constexpr bool QUAD = false;           // B operands: one ds_read_b64 per instruction
+    static __device__ __forceinline__ constexpr int k_of(int kq, int s) { return 4 * s + kq; }
     static __device__ __forceinline__ double flip(double v, uint32_t bit31) { return __hiloint2double(__double2hiint(v) ^ int(bit31), __double2loint(v)); }
 };
 template <>
@@ -959,6 +961,14 @@ struct Mfma16x4<float> {
     static constexpr int SHIFT = 2;
     static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+    // f32: the four B words a lane needs in a step are ONE 16-byte quad (a quarter of the LDS read instructions of the B
+    // side).  Lane group kq then multiplies the k values k_of(kq, 0..3); each group's four have one |k| parity -- groups
+    // 0, 1 even, 2, 3 odd -- because a quad comes from one image and the factor (-1)^(|c_hi| |k|) picks the image.
+    static constexpr bool QUAD = true;
+    static __device__ __forceinline__ constexpr int k_of(int kq, int s) {
+        constexpr int tab[4][4] = {{0, 3, 5, 6}, {9, 10, 12, 15}, {1, 2, 4, 7}, {8, 11, 13, 14}};
+        return tab[kq][s];
+    }
     static __device__ __forceinline__ float flip(float v, uint32_t bit31) { return __uint_as_float(__float_as_uint(v) ^ bit31); }
 };
 
@@ -994,15 +1004,20 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
     uint32_t ak[4], bk[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int k = 4 * s + kq;
+        const int k = MM::k_of(kq, s);
         const int a_lo = i ^ k;
         int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
         ak[s] = (uint32_t(a_lo) << ES) + (par ? NEG : 0u);
         // B side: (lane constant) ^ (step constant); lanes with odd |c_hi| take the odd-|k| words from the other image
-        bk[s] = (uint32_t(c_hi) << BS) | ((uint32_t((c_hi >> 1) & 7) << (1 + ES)) ^ (uint32_t(k) << ES));
-        if ((__builtin_popcount(uint32_t(c_hi)) & __builtin_popcount(uint32_t(k))) & 1) bk[s] ^= NEG;
+        if (MM::QUAD) {   // the lane's quad of block x: quad kq ^ (((x >> 2) & 1) << 1) (16 lanes of a b128 group: 16 bank quads)
+            bk[s] = (uint32_t(c_hi) << BS) | (uint32_t(kq ^ (((c_hi >> 2) & 1) << 1)) << 4);
+            if ((__builtin_popcount(uint32_t(c_hi)) & 1) && kq >= 2) bk[s] ^= NEG;
+        } else {
+            bk[s] = (uint32_t(c_hi) << BS) | ((uint32_t((c_hi >> 1) & 7) << (1 + ES)) ^ (uint32_t(k) << ES));
+            if ((__builtin_popcount(uint32_t(c_hi)) & __builtin_popcount(uint32_t(k))) & 1) bk[s] ^= NEG;
+        }
     }
     // block sign of every step, one bit per a_hi, and (DEGENERATE) the steps whose contribution to this column vanishes
     constexpr int SW = (H + 31) / 32, SB = H < 32 ? H : 32;   // words of step bits, steps per word
@@ -1105,12 +1120,21 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         // one step: the lane's four B words and four A words (one LDS read each), four MFMAs
         auto step = [&](int a_hi, uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff) {
             T av[4], bv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint32_t addr = b_base + (bk[s] ^ sxs);
+            if constexpr (MM::QUAD) {
+                uint32_t addr = b_base + (bk[0] ^ sxs);
                 if (DEGENERATE) addr = zero ? zero_block : addr;
-                bv[s] = *(const lds_t*)(lds + addr);
-                av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));
+                const float4v q = *(__attribute__((address_space(3))) const float4v*)(lds + addr);
+                bv[0] = q[0]; bv[1] = q[1]; bv[2] = q[2]; bv[3] = q[3];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    uint32_t addr = b_base + (bk[s] ^ sxs);
+                    if (DEGENERATE) addr = zero ? zero_block : addr;
+                    bv[s] = *(const lds_t*)(lds + addr);
+                    av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));
+                }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = MM::mma(av[s], bv[s], acc);
@@ -1120,7 +1144,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
             // n = 8, 9: all steps unrolled -- every address of a step is a lane constant the compiler keeps across items
 #pragma unroll
             for (int a_hi = 0; a_hi < H; ++a_hi) {
-                const uint32_t sx = (uint32_t(a_hi) << BS) | (uint32_t((a_hi >> 1) & 7) << (1 + ES));
+                const uint32_t sx = (uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES));
                 step(a_hi, sx | (((sign_bits[0] >> a_hi) & 1u) ? NEG : 0u), (zero_bits[0] >> a_hi) & 1u, ak, a_hi);
             }
         } else {
@@ -1139,7 +1163,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
                     const int a_hi = 32 * w + j;
-                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << BS) | (uint32_t((a_hi >> 1) & 7) << (1 + ES)));
+                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES)));
                     asm("" : "+s"(sx));   // whole, in a scalar register
                     step(a_hi, sx | (((sw[0] >> j) & 1u) << (n + ES)), (zw[0] >> j) & 1u, aw_base, j);   // NEG = 2^(n + ES) bytes
                 }

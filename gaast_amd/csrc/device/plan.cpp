@@ -577,6 +577,7 @@ struct Lowering {
             s.use_mfma = dense_kind == 3;
             s.use_mfma16 = dense_kind == 2 || dense_kind == 4;
             s.use_mfma16d = dense_kind == 4;
+            s.mfma16_quads = dense_kind == 4 && plan.dtype == GAAST_F32;   // k_gp_mfma16x4<float>: B words in 16-byte quads
             s.mfma32_pairs = dense_kind == 3 && n <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
             // blade S of the program's basis <-> blade S' of the permuted basis, e_S = sign(S) e'_S' (the parity of the
             // inversions of the new positions of S's vectors taken in ascending original order)
@@ -621,6 +622,14 @@ struct Lowering {
                 const uint32_t x = m >> 4, k = m & 15u;
                 return (x << 4) | (k ^ (((x >> 1) & 7u) << 1));
             };
+            // k_gp_mfma16x4<float>'s B image: word k of block x in quad kq(k) ^ (((x >> 2) & 1) << 1), slot s(k), with
+            // (kq, s) from the kernel's k table (Mfma16x4<float>::k_of)
+            auto mfma16q_b_pos = [](uint32_t m) {
+                static const int kq_of[16] = {0, 2, 2, 0, 2, 0, 0, 2, 3, 1, 1, 3, 1, 3, 3, 1};
+                static const int s_of[16] = {0, 0, 1, 1, 2, 2, 3, 3, 0, 0, 1, 1, 2, 2, 3, 3};
+                const uint32_t x = m >> 4, k = m & 15u;
+                return (x << 4) | (uint32_t(kq_of[k] ^ int(((x >> 2) & 1u) << 1)) << 2) | uint32_t(s_of[k]);
+            };
             auto mfma_b_pos = [](uint32_t m) {
                 const uint32_t x = m >> 5, k = m & 31;
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
@@ -642,6 +651,7 @@ struct Lowering {
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
                         const uint32_t pos = s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
                                              : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
+                                             : s.mfma16_quads ? (right ? mfma16q_b_pos(blade) : blade)
                                              : s.use_mfma16d ? (right ? mfma16d_b_pos(blade) : blade)
                                              : s.use_mfma16 ? (right ? mfma16_b_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);

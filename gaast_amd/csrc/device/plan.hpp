@@ -68,7 +68,8 @@ struct Step {
     int degenerate = 0;
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16 (f32, n = 8, 9) or k_gp_mfma16d
-    int use_mfma16d = 0; // k_gp_mfma16d (f64, n = 8, 9, 10): with use_mfma16
+    int use_mfma16d = 0; // k_gp_mfma16x4<T> (one item per workgroup): with use_mfma16
+    int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout
     int mfma32_pairs = 0;  // k_gp_mfma32p (image-pair form, f32, n = 10 ... 13) instead of k_gp_mfma32
     int spinor_lam_bit = -1, spinor_has_alpha = 0;  // index basis of the matrix-representation kernels: spinor_basis.hpp
     int use_spinor = 0;  // opt-in matrix-representation kernel (GAAST_FLAG_SPINOR_GEMM): log2 of the matrix size, or 0

@@ -104,6 +104,14 @@ static uint32_t mfma16d_b_pos(uint32_t m) {
     return (x << 4) | (k ^ (((x >> 1) & 7u) << 1));
 }
 
+// k_gp_mfma16x4<float>'s B image (plan.cpp: mfma16q_b_pos)
+static uint32_t mfma16q_b_pos(uint32_t m) {
+    static const int kq_of[16] = {0, 2, 2, 0, 2, 0, 0, 2, 3, 1, 1, 3, 1, 3, 3, 1};
+    static const int s_of[16] = {0, 0, 1, 1, 2, 2, 3, 3, 0, 0, 1, 1, 2, 2, 3, 3};
+    const uint32_t x = m >> 4, k = m & 15u;
+    return (x << 4) | (uint32_t(kq_of[k] ^ int(((x >> 2) & 1u) << 1)) << 2) | uint32_t(s_of[k]);
+}
+
 static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
                                              const char* expect_step) {
     gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
@@ -138,6 +146,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
     if (st->mfma32_pairs) for (uint32_t m = 0; m < N; ++m) inv_b[mfma32p_b_pos(m)] = m;
     else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
+    else if (st->mfma16_quads) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16q_b_pos(m)] = m;
     else if (st->use_mfma16d) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16d_b_pos(m)] = m;
     else if (st->use_mfma16) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16_b_pos(m)] = m;
     auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
