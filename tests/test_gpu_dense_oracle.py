@@ -78,6 +78,14 @@ def test_n12_degenerate_metric_null_vector_first():
     _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=1, seed=14)
 
 
+@pytest.mark.parametrize("n", [8, 10, 11])
+def test_partial_left_operand_takes_the_general_staging(n):
+    """a left operand that holds only some grades (zeros elsewhere, no 16-byte-piece fast path): k_gp_mfma16x4<float>
+    (n = 8), k_gp_mfma32p (n = 10, 11) and k_gp_mfma16x4<double> (1, 4, 8 waves per item) through their general staging"""
+    lg = [0, 1, 2, 3, 4, 5, 6] if n == 8 else [0, 1, 2, 3, 4, 5, 6, 7]   # enough entries for the dense kernels (>= 4^n / 8)
+    _check(n, [1.0] * n, lg, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma[")], batch=3, seed=40 + n)
+
+
 def test_n13_eight_waves_per_item_512_thread_kernels():
     """k_gp_mfma32<false, 512> (8 waves per item), k_gp_dense<float, false, 512>, k_gp_dense<double, false, 512>"""
     _check(13, [1.0] * 13, [0, 1, 2, 3, 4, 5], [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
