@@ -1040,7 +1040,12 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         sign_bits[w] = sb;
         zero_bits[w] = zb;
     }
-    const uint32_t b_base = 2u * NEG, zero_block = 4u * NEG;
+    // the +B / -B pair starts at 2 NEG bytes, a power of two above every bit the XOR below can touch: it rides in the lane
+    // constants (as a separate term it no longer fits the 16-bit offset field of an LDS instruction from n = 12 on in f64,
+    // and cost an extra addition per address)
+    constexpr uint32_t b_base = 2u * NEG, zero_block = 4u * NEG;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bk[s] |= b_base;
     // where this lane's results go: register r = row c_lo = MM::row(kq, r) of column c_hi
     uint32_t ooff[4], osg[4];
     bool ook[4];
@@ -1121,7 +1126,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         auto step = [&](int a_hi, uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff) {
             T av[4], bv[4];
             if constexpr (MM::QUAD) {
-                uint32_t addr = b_base + (bk[0] ^ sxs);
+                uint32_t addr = bk[0] ^ sxs;
                 if (DEGENERATE) addr = zero ? zero_block : addr;
                 const float4v q = *(__attribute__((address_space(3))) const float4v*)(lds + addr);
                 bv[0] = q[0]; bv[1] = q[1]; bv[2] = q[2]; bv[3] = q[3];
@@ -1130,7 +1135,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    uint32_t addr = b_base + (bk[s] ^ sxs);
+                    uint32_t addr = bk[s] ^ sxs;
                     if (DEGENERATE) addr = zero ? zero_block : addr;
                     bv[s] = *(const lds_t*)(lds + addr);
                     av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));

@@ -13,7 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-HIP_KERNEL = {"r12": "k_gp_mfma32", "r8": "k_gp_mfma16", "cl41": "gaast_jit", "cl41g1": "gaast_jit", "r12s": "k_gp_spinor12s"}
+HIP_KERNEL = {"r12": "k_gp_mfma32p", "r8": "k_gp_mfma16x4<float>", "cl41": "gaast_jit", "cl41g1": "gaast_jit", "r12s": "k_gp_spinor12s",
+              "r12d": "k_gp_mfma16x4<double>", "r8d": "k_gp_mfma16x4<double>"}
 
 
 def main():
