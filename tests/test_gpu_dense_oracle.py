@@ -105,6 +105,47 @@ def test_n8_n9_any_diagonal_metric_stays_on_the_dense_kernels(metric):
     _check(n, metric, None, variants, batch=9, seed=80 + n)
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_dense_products_on_the_default_path(chunk):
+    """Randomised: n = 8, 9, both value types, random +-1 / 0 metrics (at least five non-null vectors), operands that miss
+    one or two grades, a random projection of the result, a shared (batch-1) operand now and then -- the matrix-core kernels'
+    maps, basis permutation, general staging and result maps against the oracle, within 4 eps sum |terms|"""
+    rng = np.random.default_rng(7000 + chunk)
+    dense_cases = 0
+    for case in range(6):
+        n = int(rng.choice([8, 9]))
+        dtype = ga.F32 if rng.random() < 0.5 else ga.F64
+        while True:
+            metric = [float(x) for x in rng.choice([1.0, -1.0, 0.0], size=n, p=[0.5, 0.35, 0.15])]
+            if sum(m != 0.0 for m in metric) >= 5:
+                break
+        allg = list(range(n + 1))
+        lg = sorted(set(allg) - set(int(g) for g in rng.choice(allg, size=int(rng.integers(0, 2)), replace=False)))
+        rg = sorted(set(allg) - set(int(g) for g in rng.choice(allg, size=int(rng.integers(0, 2)), replace=False)))
+        og_sel = sorted(set(allg) - set(int(g) for g in rng.choice(allg, size=int(rng.integers(0, 3)), replace=False)))
+        batch = int(rng.integers(1, 12))
+        shared = rng.random() < 0.3
+        build = lambda B, lg=lg, rg=rg, og_sel=og_sel, n=n: (B.input(0, lg, n) * B.input(1, rg, n)).gselect(og_sel)
+        rows = {0: rows_of(n, lg, 1 if shared else batch, rng, np.float32), 1: rows_of(n, rg, batch, rng, np.float32)}
+        rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+        want, wmask = oracle_eval_batch(build, metric, rows64, batch)
+        got, mask, spec = hip_eval_batch(build, metric, rows if dtype == ga.F32 else rows64, batch, dtype=dtype)
+        where = (n, dtype, metric, lg, rg, og_sel, batch, shared, spec.launches())
+        assert mask == wmask, where
+        if not any("product_dense" in l for l in spec.launches()):
+            assert np.array_equal(got.astype(np.float64), want) or dtype == ga.F32, where   # exact list kernels
+            continue
+        dense_cases += 1
+        og = [k for k in range(n + 1) if (wmask >> k) & 1]
+        eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+        for i in range(batch):
+            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][0 if shared else i]), row_to_bits(n, rg, rows64[1][i]))
+            bound = 4 * eps * bits_to_row(n, og, S) + 1e-300
+            err = np.abs(got[i].astype(np.float64) - want[i])
+            assert np.all(err <= bound), (where, i, float((err / bound).max()))
+    assert dense_cases >= 4, dense_cases     # the draw is meant to land on the dense kernels
+
+
 def test_dense_kernels_need_enough_non_null_vectors():
     """six null vectors out of eight leave fewer than four non-null lo candidates: the product stays on the exact list
     kernels (still correct, bit-exact)"""
