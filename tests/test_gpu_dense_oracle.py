@@ -107,13 +107,13 @@ def test_n8_n9_any_diagonal_metric_stays_on_the_dense_kernels(metric):
 
 @pytest.mark.parametrize("chunk", range(4))
 def test_random_dense_products_on_the_default_path(chunk):
-    """Randomised: n = 8, 9, both value types, random +-1 / 0 metrics (at least five non-null vectors), operands that miss
+    """Randomised: n = 8, 9, 10, both value types, random +-1 / 0 metrics (at least five non-null vectors), operands that miss
     one or two grades, a random projection of the result, a shared (batch-1) operand now and then -- the matrix-core kernels'
     maps, basis permutation, general staging and result maps against the oracle, within 4 eps sum |terms|"""
     rng = np.random.default_rng(7000 + chunk)
     dense_cases = 0
     for case in range(6):
-        n = int(rng.choice([8, 9]))
+        n = int(rng.choice([8, 9, 10]))
         dtype = ga.F32 if rng.random() < 0.5 else ga.F64
         while True:
             metric = [float(x) for x in rng.choice([1.0, -1.0, 0.0], size=n, p=[0.5, 0.35, 0.15])]
