@@ -29,6 +29,7 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 GATHER_WATCHDOG_S = 240     # the multi-GPU gather legs give up after this long (the throughput line is printed regardless)
+GATHER_FAILED_EXIT = 3      # ... and the job then ends with this status: a hung or failed exchange is a FAILED run
 
 
 def workload_spec(name):
@@ -307,11 +308,17 @@ def main():
         ones = torch.ones(1, dtype=torch.int64, device="cpu" if rehearsal else dev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
-        if not rehearsal:
+        # rehearsal only: the test transport (tests/cpp/rccl_stub.c, built by the test) stands in for RCCL, which refuses
+        # ranks that share a device -- so that the LIBRARY's gather runs, not a torch.distributed stand-in
+        transport = os.environ.get("GAAST_BENCH_REHEARSAL_TRANSPORT") if rehearsal else None
+        if transport:
+            ga._lib.check(L.gaast_hip_comm_set_library(transport.encode()))
+        if not rehearsal or transport:
             # the library's own communicator (what a Rust host would use: include/gaast_hip.h, multi-GPU): the
             # 128-byte id travels over the rendezvous torch.distributed already provides
             # (a failure here is reported in the JSON and the gather falls back to torch.distributed: the throughput
             # line must not depend on it)
+            cdev = "cpu" if rehearsal else dev
             idbuf = (C.c_ubyte * ga._lib.COMM_ID_BYTES)()
             ok = 1
             if rank == 0:
@@ -319,7 +326,7 @@ def main():
                     ga._lib.check(L.gaast_hip_comm_unique_id(idbuf))
                 except ga.GaastError as e:
                     ok, lib_comm_error = 0, str(e)
-            idt = torch.tensor(list(bytes(idbuf)) + [ok], dtype=torch.uint8, device=dev)
+            idt = torch.tensor(list(bytes(idbuf)) + [ok], dtype=torch.uint8, device=cdev)
             dist.broadcast(idt, src=0)
             vals = idt.cpu().tolist()
             if vals[-1]:
@@ -334,7 +341,7 @@ def main():
             else:
                 joined = 0
             # every rank must agree on which path the gather takes
-            agree = torch.tensor([joined], dtype=torch.int64, device=dev)
+            agree = torch.tensor([joined], dtype=torch.int64, device=cdev)
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
             lib_comm = bool(agree.item())
             if not lib_comm and lib_comm_error is None:
@@ -530,7 +537,7 @@ def main():
             "vs_baseline": None, "dtype": wl["dtname"], "data": "synthetic",
             "global_batch": global_batch,
             **({"rccl_ranks": rccl_ranks} if world > 1 else {}),
-            **({"rehearsal": "ranks share GPUs, gloo collectives: control-flow check only, not a measurement"} if rehearsal else {}),
+            **({"rehearsal": "ranks share GPUs, gloo / test-transport collectives: control-flow check only, not a measurement"} if rehearsal else {}),
             "config": {"workload": label, "dim": n, "batch_per_gpu": batch, "global_batch": global_batch,
                        "shards": counts, "launches_per_eval": launches, "specialize_s": t_spec},
             "roofline": roof,
@@ -560,7 +567,8 @@ def main():
 
             def overlapped():
                 spec.eval_gather(ins, out, gathered, counts, root=0, n_chunks=chunks)
-            path = "gaast_hip_eval_gather / gaast_hip_gather_rows: RCCL send/recv, one direct transfer per peer"
+            path = ("gaast_hip_eval_gather / gaast_hip_gather_rows: RCCL send/recv, one direct transfer per peer" if not rehearsal else
+                    "gaast_hip_eval_gather / gaast_hip_gather_rows over the TEST transport (tests/cpp/rccl_stub.c: ranks share a GPU)")
         else:
             # rehearsal (ranks share a GPU, RCCL refuses that: gloo on host copies) or no library communicator
             # (torch.distributed's own RCCL on device tensors): the same chunk schedule with torch collectives
@@ -592,8 +600,8 @@ def main():
                     h.wait()
             path = ("torch.distributed gather of host copies (rehearsal: ranks share a GPU)" if rehearsal else
                     "torch.distributed gather on device tensors (library communicator unavailable: " + str(lib_comm_error) + ")")
-        # The gather legs run over a communicator that cannot be rehearsed on a one-GPU box: if they hang or fail, the
-        # throughput line measured above is still printed (gather.error says what happened) and the job ends cleanly.
+        # If the gather legs hang or fail, the throughput line measured above is still printed (gather.error says what
+        # happened) -- and the job ends with status GATHER_FAILED_EXIT, so that the launcher and the driver see a failure.
         import threading
         state = {"done": False}
 
@@ -603,11 +611,13 @@ def main():
             if rank == 0:
                 emit({"path": path, "library_communicator": lib_comm, "chunks": chunks,
                       "error": f"gather legs did not finish within {GATHER_WATCHDOG_S} s; throughput above is unaffected"})
-            os._exit(0)
+            os._exit(GATHER_FAILED_EXIT)
         watchdog = threading.Timer(GATHER_WATCHDOG_S, give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
+            if rehearsal and os.environ.get("GAAST_BENCH_FAIL_GATHER") == "1":     # test hook: the failure path
+                raise RuntimeError("injected gather failure (GAAST_BENCH_FAIL_GATHER)")
             blocking()
             overlapped()
             w_block = timed(blocking, args.steps)
@@ -634,7 +644,9 @@ def main():
     if rank == 0:
         emit(gather)
     if gather is not None and "error" in gather:
-        os._exit(0)          # some rank may be stuck in a collective: no further rendezvous
+        sys.stderr.write(f"rank {rank}: gather failed: {gather['error']}\n")
+        sys.stderr.flush()
+        os._exit(GATHER_FAILED_EXIT)          # some rank may be stuck in a collective: no further rendezvous
     if world > 1:
         dist.barrier()
         if lib_comm:

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gaast_hip_eval": (_ci, [_vp, C.POINTER(_vp), _ci, _i64, _vp]),
     "gaast_hip_program_jit_source": (C.c_char_p, [_vp]),
     "gaast_hip_program_domain_errors": (_ci, [_vp, C.POINTER(_i64)]),
+    "gaast_hip_comm_set_library": (_ci, [C.c_char_p]),
     "gaast_hip_comm_unique_id": (_ci, [_vp]),
     "gaast_hip_comm_init": (_ci, [_vp, _ci, _ci]),
     "gaast_hip_comm_destroy": (_ci, []),

@@ -22,6 +22,7 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+std::string g_library;   // comm_set_library: the file to load instead of the system's librccl
 
 template <typename F>
 bool sym(void* so, const char* name, F* out) {
@@ -31,13 +32,24 @@ bool sym(void* so, const char* name, F* out) {
 
 int load(std::string* err) {
     if (g_rccl.so) return 0;
-    // the soname first: a copy already mapped by the host process (torch ships one) is reused
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) {
-        *err = std::string("cannot load librccl: ") + dlerror();
-        return 1;
+    void* so = nullptr;
+    if (!g_library.empty()) {
+        // the host named the transport (gaast_hip_comm_set_library): that file or nothing; RTLD_LOCAL keeps its
+        // nccl* symbols away from a librccl the process may also have mapped
+        so = dlopen(g_library.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!so) {
+            *err = std::string("cannot load ") + g_library + ": " + dlerror();
+            return 1;
+        }
+    } else {
+        // the soname first: a copy already mapped by the host process (torch ships one) is reused
+        so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!so) {
+            *err = std::string("cannot load librccl: ") + dlerror();
+            return 1;
+        }
     }
     Rccl r;
     r.so = so;
@@ -47,7 +59,8 @@ int load(std::string* err) {
                     sym(so, "ncclGroupStart", &r.GroupStart) && sym(so, "ncclGroupEnd", &r.GroupEnd) &&
                     sym(so, "ncclGetErrorString", &r.GetErrorString);
     if (!ok) {
-        *err = "librccl lacks an expected symbol";
+        *err = (g_library.empty() ? std::string("librccl") : g_library) + " lacks an expected nccl* symbol";
+        dlclose(so);
         return 1;
     }
     g_rccl = r;
@@ -68,6 +81,18 @@ int fail(const char* what, ncclResult_t r, std::string* err) {
 ncclDataType_t dt(int elem_size) { return elem_size == 4 ? ncclFloat32 : ncclFloat64; }
 
 }  // namespace
+
+int comm_set_library(const char* path, std::string* err) {
+    const std::string want = path ? path : "";
+    if (g_rccl.so && want != g_library) {
+        *err = "a collective library is already loaded (" + (g_library.empty() ? std::string("librccl") : g_library) + ")";
+        return 1;
+    }
+    g_library = want;
+    return 0;
+}
+
+const char* comm_library() { return g_library.c_str(); }
 
 int comm_unique_id(void* id128, std::string* err) {
     if (load(err)) return 1;

@@ -18,6 +18,10 @@ struct Comm {
 };
 
 // All return 0 on success; on failure *err describes the RCCL / loader error.
+// Which shared object provides the nccl* entry points: NULL / "" = the system's librccl (default).  Must come before the
+// first use; fails once another library has been loaded.
+int comm_set_library(const char* path, std::string* err);
+const char* comm_library();
 int comm_unique_id(void* id128, std::string* err);
 int comm_init(Comm& c, const void* id128, int rank, int world, std::string* err);
 int comm_destroy(Comm& c, std::string* err);

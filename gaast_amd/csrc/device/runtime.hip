@@ -1109,6 +1109,12 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n
     return eval_range(prog, in_bound, out, 0, batch);
 }
 
+int gaast_hip_comm_set_library(const char* path) {
+    std::string err;
+    if (comm_set_library(path, &err)) return rccl_err(err);
+    return GAAST_OK;
+}
+
 int gaast_hip_comm_unique_id(void* id_out) {
     if (!id_out) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
     if (int st = ensure_init()) return st;
@@ -1182,18 +1188,31 @@ int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs
     if (int st = bind_eval(prog, inputs, n_inputs, batch, out, in_bound)) return st;
     // chunk c is computed on the library stream; its rows leave on the communicator's stream while chunk c + 1 is
     // being computed.  Every rank walks all n_chunks steps (a rank with fewer items has empty chunks) so that
-    // sends and receives pair up.
+    // sends and receives pair up -- also after a local failure: the remaining transfers are still posted (of whatever
+    // the rows hold) so that no peer is left waiting in a receive, and the first error is returned afterwards.
+    int first_error = GAAST_OK;
+    std::string first_msg;
+    auto note = [&](int st) {
+        if (st != GAAST_OK && first_error == GAAST_OK) {
+            first_error = st;
+            first_msg = g_err;
+        }
+        return st;
+    };
     for (int c = 0; c < n_chunks; ++c) {
         int64_t lo, hi;
         chunk_span(batch, n_chunks, c, &lo, &hi);
-        if (int st = eval_range(prog, in_bound, out, lo, hi - lo)) return st;
+        if (first_error == GAAST_OK) note(eval_range(prog, in_bound, out, lo, hi - lo));
         hipEvent_t ev;
-        if (int st = chunk_event(c, &ev)) return st;
-        HIP_TRY(hipEventRecord(ev, g_stream));
-        HIP_TRY(hipStreamWaitEvent(g_comm.stream, ev, 0));
-        if (int st = gather_chunk(out, gathered, counts, root, n_chunks, c)) return st;
+        if (note(chunk_event(c, &ev)) == GAAST_OK) {
+            if (hipEventRecord(ev, g_stream) != hipSuccess || hipStreamWaitEvent(g_comm.stream, ev, 0) != hipSuccess)
+                note(set_err(GAAST_ERR_HIP, "gaast_hip_eval_gather: chunk event"));
+        }
+        note(gather_chunk(out, gathered, counts, root, n_chunks, c));
     }
-    return join_comm_stream();
+    note(join_comm_stream());
+    if (first_error != GAAST_OK) return set_err(first_error, first_msg);
+    return GAAST_OK;
 }
 
 }  // extern "C"

@@ -223,6 +223,12 @@ int gaast_hip_eval(gaast_hip_program_t prog, const gaast_hip_mv_t *inputs, int n
  * (collective).  librccl is loaded on first use (dlopen), not at link time.
  */
 #define GAAST_COMM_ID_BYTES 128
+/* Which shared object provides the nccl* entry points the gather uses (ncclGetUniqueId, ncclCommInitRank,
+ * ncclCommDestroy, ncclSend, ncclRecv, ncclAllReduce, ncclGroupStart, ncclGroupEnd, ncclGetErrorString): NULL = the
+ * system's librccl (default: soname lookup, then /opt/rocm/lib).  For hosts that ship their own RCCL build and for the
+ * test transport that lets several ranks share one GPU (tests/cpp/rccl_stub.c).  Call before the first
+ * gaast_hip_comm_* use; GAAST_ERR_RCCL once another library has been loaded. */
+int gaast_hip_comm_set_library(const char *path);
 int gaast_hip_comm_unique_id(void *id_out);
 int gaast_hip_comm_init(const void *id, int rank, int world);
 int gaast_hip_comm_destroy(void);

@@ -1145,7 +1145,9 @@ static void ext_exp_log(const og_spec *s, int res_id, int this_id, cache *c) {
         if (!r0) return;
         r0[0] = r0[0] + c0;
     }
-    if (og_gs_contains(mine, k) && !(is_exp && k == 0)) {
+    /* exp of a bare scalar (k = 0; grade_set.rs:181 allows it): the two statements land in the same component,
+     * r0 = (r0 + cosh|a|) + (sinh|a| / |a|) a = e^a */
+    if (og_gs_contains(mine, k)) {
         double *rk = grade_slice_mut(res, (size_t)k, &c->status);
         if (!rk) return;
         const size_t len = res->len[k] < m ? res->len[k] : m;

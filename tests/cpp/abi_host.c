@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include "gaast_hip.h"
+#include "cfg5_program.h"
 
 #define TRY(call)                                                                             \
     do {                                                                                      \
@@ -31,43 +32,11 @@ int main(int argc, char **argv) {
     }
     const int64_t batch = atoll(argv[3]);
     const int use_gather = argc > 4 && strcmp(argv[4], "gather") == 0;
-    const int n = 5;
-    const double metric[5] = {1.0, 1.0, 1.0, 1.0, -1.0};
-    const uint64_t EVEN = 0x15, VEC = 0x2, ODD = 0x2A; /* grades {0,2,4}, {1}, {1,3,5} */
-
-    /* post-order node list: R, X, R*X, ~R, (R*X)*~R; R is one shared node (Expr::clone shares the Rc, expr.rs:47-53) */
-    gaast_node_desc nodes[5];
-    memset(nodes, 0, sizeof nodes);
-    for (int i = 0; i < 5; ++i) {
-        nodes[i].child0 = nodes[i].child1 = -1;
-        nodes[i].vec_space_dim = n;
-        nodes[i].input_slot = -1;
-        nodes[i].product_kind = GAAST_PROD_EXPLICIT;
-    }
-    nodes[0].opcode = GAAST_OP_INPUT;   nodes[0].minimal_grade_mask = EVEN; nodes[0].input_slot = 0;
-    nodes[1].opcode = GAAST_OP_INPUT;   nodes[1].minimal_grade_mask = VEC;  nodes[1].input_slot = 1;
-    nodes[2].opcode = GAAST_OP_PRODUCT; nodes[2].minimal_grade_mask = ODD;  nodes[2].child0 = 0; nodes[2].child1 = 1;
-    nodes[2].product_kind = GAAST_PROD_GEOMETRIC; nodes[2].n_comp_muls = 80;   /* compact: the library regenerates the list */
-    nodes[3].opcode = GAAST_OP_REVERSE; nodes[3].minimal_grade_mask = EVEN; nodes[3].child0 = 0;
-    nodes[4].opcode = GAAST_OP_PRODUCT; nodes[4].minimal_grade_mask = ODD;  nodes[4].child0 = 2; nodes[4].child1 = 3;
-    nodes[4].product_kind = GAAST_PROD_GEOMETRIC; nodes[4].n_comp_muls = 256;
-
-    gaast_input_desc inputs[2];
-    memset(inputs, 0, sizeof inputs);
-    inputs[0].grade_mask = EVEN; inputs[0].storage_dim = n;
-    inputs[1].grade_mask = VEC;  inputs[1].storage_dim = n;
-
-    gaast_program_desc desc;
-    memset(&desc, 0, sizeof desc);
-    desc.vec_space_dim = n;
-    desc.metric_diag = metric;
-    desc.dtype = GAAST_F64;
-    desc.n_nodes = 5;
-    desc.nodes = nodes;
-    desc.root = 4;
-    desc.n_inputs = 2;
-    desc.inputs = inputs;
-    desc.flags = 0;
+    const int n = CFG5_N;
+    const uint64_t EVEN = CFG5_EVEN, VEC = CFG5_VEC, ODD = CFG5_ODD; /* grades {0,2,4}, {1}, {1,3,5} */
+    static cfg5_program cfg;
+    cfg5_fill(&cfg);
+#define desc cfg.desc
 
     const int dev = 0;
     TRY(gaast_hip_init(&dev, 1));

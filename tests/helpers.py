@@ -192,3 +192,30 @@ def abs_terms_bound(n, A_bits, B_bits):
         return v
     N = 1 << n
     return np.abs(wht(wht(np.abs(A_bits)) * wht(np.abs(B_bits))) / N)
+
+
+# ---- C hosts and the test transport (tests/cpp) ---------------------------------------------------------------------
+def build_c_host(name, out_dir):
+    """gcc a plain C host of the ABI (tests/cpp/<name>.c) against include/gaast_hip.h and libgaast_hip.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gaast_amd", "lib")
+    exe = os.path.join(str(out_dir), name)
+    subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(root, "tests", "cpp"), os.path.join(root, "tests", "cpp", name + ".c"),
+                    "-L", libdir, "-lgaast_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def build_rccl_stub(out_dir):
+    """The TEST-ONLY transport with the nccl* entry points the library resolves (tests/cpp/rccl_stub.c): lets several
+    ranks share one GPU, which RCCL refuses.  Returns the path to hand to gaast_hip_comm_set_library."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(str(out_dir), "librccl_stub.so")
+    subprocess.run(["gcc", "-std=gnu11", "-shared", "-fPIC", "-O1", "-Wall", "-Wextra", "-Werror", "-fvisibility=hidden",
+                    "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "cpp", "rccl_stub.c"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-Bsymbolic", "-Wl,-rpath,/opt/rocm/lib", "-o", so], check=True)
+    return so

@@ -30,12 +30,18 @@ def test_bench_prints_one_json_line(args, bound):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
-def test_bench_self_launches_two_ranks_and_gathers(tmp_path):
+@pytest.mark.parametrize("with_transport", [True, False])
+def test_bench_self_launches_two_ranks_and_gathers(tmp_path, with_transport):
     """`python bench.py --gpus 2` with NO launcher: the parent starts the ranks before touching a GPU.  Rehearsal mode
-    (both ranks on this box's one GPU, gloo collectives) exercises the real N > 1 control flow: shards, the chunked
-    overlapped gather, max-over-ranks timing, one JSON line from rank 0."""
+    (both ranks on this box's one GPU) exercises the real N > 1 control flow: shards, the chunked overlapped gather,
+    max-over-ranks timing, one JSON line from rank 0.  With the test transport the gather is the LIBRARY's
+    (gaast_hip_eval_gather / gaast_hip_gather_rows, `library_communicator: true`); without it the torch.distributed
+    stand-in over gloo."""
+    from helpers import build_rccl_stub
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["GAAST_BENCH_REHEARSAL"] = "1"
+    if with_transport:
+        env["GAAST_BENCH_REHEARSAL_TRANSPORT"] = build_rccl_stub(tmp_path)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--batch", "300"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -46,8 +52,26 @@ def test_bench_self_launches_two_ranks_and_gathers(tmp_path):
     assert d["n_gpus"] == 2 and d["global_batch"] == 600 and d["rccl_ranks"] == 2 and "rehearsal" in d
     assert d["config"]["shards"] == [300, 300]
     g = d["gather"]
+    assert "error" not in g, g
     assert g["chunks"] == 4 and g["value_with_gather"] > 0 and g["value_with_blocking_gather"] > 0
     assert g["bytes_per_rank"] == 300 * 4096 * 4
+    assert g["library_communicator"] is with_transport
+    if with_transport:
+        assert g["gathered_rows"] == 600
+
+
+def test_a_failed_gather_ends_the_job_non_zero(tmp_path):
+    """A hung or failed exchange is a FAILED run: the throughput line is still printed (gather.error), the status is
+    GATHER_FAILED_EXIT.  Provoked with a transport file that does not exist on rank 1 only... every rank then agrees to
+    fall back -- so instead the failure is injected where the legs run: GAAST_BENCH_FAIL_GATHER=1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GAAST_BENCH_REHEARSAL"] = "1"
+    env["GAAST_BENCH_FAIL_GATHER"] = "1"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--batch", "64"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert run.returncode == 3, (run.returncode, run.stderr[-2000:])
+    d = json.loads([l for l in run.stdout.splitlines() if l.strip()][0])
+    assert d["value"] > 0 and "error" in d["gather"]
 
 
 def test_bench_default_multi_gpu_workload_is_config_4(monkeypatch):

@@ -96,6 +96,47 @@ def test_vectors_and_pseudoscalars_need_no_domain_check():
     _check(lambda B: B.input(0, [3], 3).exp(), 3, rows, 50)
 
 
+@pytest.mark.parametrize("flags,kernel", [(0, "ast_jit"), (ga.FLAG_NO_FUSION, "exponential")])
+@pytest.mark.parametrize("dtype", [ga.F64, ga.F32])
+def test_exp_of_a_bare_scalar_through_the_raw_abi(flags, kernel, dtype):
+    """Phases 1-3 refuse exp(scalar) like the reference (test_oracle_explog.py), but a host can hand the flat program
+    over: INPUT {0} -> EXP {0}.  Both statements of the extension land in grade 0: cosh|a| + (sinh|a| / |a|) a = e^a
+    (round 2 returned cosh|a|).  Checked against exp itself within 8 eps e^|a| on both kernels, a of either sign and 0."""
+    import ctypes as C
+    from gaast_amd import _lib
+    L = _lib.lib()
+    _lib.init_device()
+    nodes = (_lib.NodeDesc * 2)()
+    for nd in nodes:
+        nd.child0 = nd.child1 = nd.input_slot = -1
+        nd.vec_space_dim, nd.minimal_grade_mask, nd.product_kind = 3, 1, _lib.PROD_EXPLICIT
+    nodes[0].opcode, nodes[0].input_slot = _lib.OP_INPUT, 0
+    nodes[1].opcode, nodes[1].child0 = _lib.OP_EXP, 0
+    inputs = (_lib.InputDesc * 1)()
+    inputs[0].grade_mask, inputs[0].storage_dim = 1, 3
+    metric = (C.c_double * 3)(1.0, 1.0, 1.0)
+    desc = _lib.ProgramDesc()
+    desc.vec_space_dim, desc.metric_diag, desc.dtype = 3, metric, dtype
+    desc.n_nodes, desc.nodes, desc.root = 2, nodes, 1
+    desc.n_inputs, desc.inputs, desc.flags = 1, inputs, ga.FLAG_EXP_LOG | flags
+    prog = C.c_void_p()
+    _lib.check(L.gaast_hip_program_create(C.byref(desc), C.byref(prog)))
+    names = [L.gaast_hip_program_launch_name(prog, i).decode() for i in range(L.gaast_hip_program_num_launches(prog))]
+    assert any(kernel in x for x in names), names
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    a = np.concatenate([np.random.default_rng(8).uniform(-3, 3, 62), [0.0, -0.5]]).astype(npdt).reshape(64, 1)
+    mv_in = ga.DeviceMV.from_rows(3, [0], a, dtype=dtype)
+    out = ga.DeviceMV.alloc(3, ga.GradeSet(1), 64, dtype)
+    _lib.check(L.gaast_hip_eval(prog, (C.c_void_p * 1)(mv_in._h), 1, 64, out._h))
+    _lib.check(L.gaast_hip_synchronize())
+    got = out.download_rows().astype(np.float64)
+    _lib.check(L.gaast_hip_program_destroy(prog))
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+    want = np.exp(a.astype(np.float64))
+    assert np.all(np.abs(got - want) <= 8 * eps * np.exp(np.abs(a))), float(np.abs(got - want).max())
+    assert got[62, 0] == 1.0
+
+
 @pytest.mark.parametrize("flags", [0, ga.FLAG_NO_FUSION])
 def test_bivectors_whose_square_is_not_scalar_are_counted(flags):
     """R^4: e12 + e34 squares to -2 + 2 e1234.  The oracle refuses such an item (OG_PANIC_DOMAIN); the device counts it

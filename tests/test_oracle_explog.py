@@ -98,6 +98,20 @@ def test_null_and_hyperbolic_generators():
     del B
 
 
+def test_exp_of_a_bare_scalar_is_a_reference_panic_at_specialization():
+    """grade_set.rs:181 lets `exp` through on a grade-0 operand (maximal set {0}), but specialization hands the child
+    `wanted.log()` (specialize.rs:91) and {0}.log() asserts (grade_set.rs:190-197): upstream panics, so do the oracle and
+    the host mirror.  Only a hand-built flat program can reach the evaluation of exp(scalar): there the extension
+    computes e^a (tests/test_gpu_explog.py::test_exp_of_a_bare_scalar_through_the_raw_abi)."""
+    with pytest.raises(og.OraclePanic) as ei:
+        og.mv(og.GradeMapMV({0: [0.75]})).exp().specialize(3)
+    assert "log can only be used" in str(ei.value)
+    import gaast_amd as ga
+    with pytest.raises(ga.GaastError) as ei:
+        ga.mv(ga.Input(0, [0], 3)).exp().specialize(3)
+    assert "log can only be used" in str(ei.value)
+
+
 def test_a_bivector_whose_square_is_not_scalar_is_refused():
     B = {2: np.array([1.0, 0.0, 0.0, 0.0, 0.0, 1.0])}        # e12 + e34 in R^4: B B has an e1234 part
     with pytest.raises(og.OraclePanic) as ei:
