@@ -72,6 +72,8 @@ struct DenseArgs {
     uint32_t neg_lo;            // lo basis vectors that square to -1
     int beta;
     int out_rows;               // k_gp_mfma16: every blade is produced into 16-byte aligned rows of 2^n words, beta = 0
+    int left_signs;             // some left_map word has its negate bit set (folded sign arms, permuted basis)
+    int out_signs;              // some out_map word has its sign bit set (permuted basis)
     int64_t batch;
 };
 
@@ -974,12 +976,20 @@ struct Mfma16x4<float> {
 
 // k_gp_mfma16x4<T, ...>: T = double is the kernel the documents call k_gp_mfma16d; T = float is the same kernel on
 // v_mfma_f32_16x16x4_f32 (one item per workgroup instead of k_gp_mfma16's four items per instruction).
-// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): a thread moves its 16-byte
-// pieces of every row (f64: two per row, f32: one), their map words (image address, sign) stay in registers, and the rows
-// of the NEXT item are fetched into registers while the matrix cores work on the current one.  Otherwise: the general
-// staging.
-template <typename T, bool DEGENERATE, int NDIM, bool FAST>
+// MODE >= 1 (FAST): both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): a thread moves
+// its 16-byte pieces of every row (f64: two per row, f32: one), their map words (image address, sign) stay in registers,
+// and the rows of the NEXT item are fetched into registers while the matrix cores work on the current one.  MODE 0: the
+// general staging.  MODE 2: in addition every blade is produced and nothing is accumulated (beta = 0, the host checks):
+// the result stores are straight-line code -- no per-register branches, (uniform row base) + (lane offset) addressing,
+// and, because their number is known, the wait for the prefetched rows no longer waits for the previous item's stores
+// (loads and stores share one in-order counter).
+// The FAST staging does not apply the `0.0 + x` of the reference's zero-init + add_grades_from copy: it only turns -0.0
+// into +0.0, and in these kernels a zero operand of either sign contributes +-0 to a sum that starts from +0.0 and is
+// rounded to nearest, which leaves every sum -- also an all-zero one: (+0) + (-0) = +0 -- bit for bit what it would be
+// (tests/test_gpu_dense_oracle.py::test_negative_zero_operands_leave_no_trace).
+template <typename T, bool DEGENERATE, int NDIM, int MODE>
 __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p) {
+    constexpr bool FAST = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
@@ -990,11 +1000,27 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
     constexpr int N = 1 << n;
     constexpr int H = 1 << (n - 4);               // number of 16-blocks
     constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
-    constexpr int item_stride = 4 * N + 16;       // elements: +A, -A, +B, -B images, 16 zeros
-    constexpr uint32_t NEG = uint32_t(N) << ES;   // bytes from an image to its negated copy
+    // LDS layout (elements), n <= 9: +B [0, N), -B [N, 2 N), +A [2 N, 3 N), 16 spare, -A [3 N + 16, 4 N + 16), 16 zeros.
+    // The B pair starts at a multiple of 2 N and its halves are N apart, a power of two: the B sign is an address BIT (XOR).
+    // -A sits one 16-block further than N from +A: the two 16-lane groups that share a bank cycle of an A read want the
+    // same 16 words of a block, with signs of their own -- +A[w] and -A[w] N apart are two addresses in ONE bank (a 2-way
+    // conflict on nearly every A read: 128 of the 420 LDS cycles an item cost at n = 8 in round 2), N + 16 apart they are
+    // in different halves of the banks.  n >= 10: +A, -A, +B, -B, 16 zeros as before -- measured: the split gains 1 % at
+    // n = 8, 9, nothing at n = 10, 11, and with the A pair above 64 KiB (n = 12, f64) the kernel LOSES 6 % (same box:
+    // 8.23 -> 8.71 ms per 16,384 items, with or without the extra block), so the B pair keeps the upper half there and
+    // rides in the lane constants (as a separate term it does not fit the 16-bit offset field of an LDS instruction).
+#ifndef GAAST_MFMA16X4_PAD_MAXN
+#define GAAST_MFMA16X4_PAD_MAXN 9    /* the -A image sits one block further up to this dimension (A/B switch) */
+#endif
+    constexpr int PAD_A = NDIM <= GAAST_MFMA16X4_PAD_MAXN ? 16 : 0;
+    constexpr int A_EL = PAD_A ? 2 * N : 0, B_EL = PAD_A ? 0 : 2 * N;   // first element of the +A / +B image
+    constexpr int item_stride = 4 * N + 32;
+    constexpr uint32_t NEG = uint32_t(N) << ES;   // bytes from +B to -B
+    constexpr uint32_t A_BASE = uint32_t(A_EL) << ES, NEG_A = uint32_t(N + PAD_A) << ES;   // bytes: +A, and from +A to -A
+    constexpr uint32_t B_BASE = uint32_t(B_EL) << ES;
     constexpr int BS = 4 + ES;                    // log2 of a 16-block's bytes
     const int tid = threadIdx.x;
-    if (tid < 16) smem[4 * N + tid] = T(0);       // the B "block" of a vanishing contribution: zero for the whole launch
+    if (tid < 16) smem[4 * N + PAD_A + tid] = T(0);  // the B "block" of a vanishing contribution: zero for the whole launch
 
     const int tile = tid >> 6, lane = tid & 63;
     const int i = lane & 15, kq = lane >> 4;
@@ -1009,7 +1035,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
         for (int pp = 1; pp < 4; ++pp)
             if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-        ak[s] = (uint32_t(a_lo) << ES) + (par ? NEG : 0u);
+        ak[s] = A_BASE + (uint32_t(a_lo) << ES) + (par ? NEG_A : 0u);
         // B side: (lane constant) ^ (step constant); lanes with odd |c_hi| take the odd-|k| words from the other image
         if (MM::QUAD) {   // the lane's quad of block x: quad kq ^ (((x >> 2) & 1) << 1) (16 lanes of a b128 group: 16 bank quads)
             bk[s] = (uint32_t(c_hi) << BS) | (uint32_t(kq ^ (((c_hi >> 2) & 1) << 1)) << 4);
@@ -1040,12 +1066,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         sign_bits[w] = sb;
         zero_bits[w] = zb;
     }
-    // the +B / -B pair starts at 2 NEG bytes, a power of two above every bit the XOR below can touch: it rides in the lane
-    // constants (as a separate term it no longer fits the 16-bit offset field of an LDS instruction from n = 12 on in f64,
-    // and cost an extra addition per address)
-    constexpr uint32_t b_base = 2u * NEG, zero_block = 4u * NEG;
+    constexpr uint32_t zero_block = uint32_t(4 * N + PAD_A) << ES;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bk[s] |= b_base;
+    for (int s = 0; s < 4; ++s) bk[s] |= B_BASE;   // a multiple of 2 N elements: above every bit the XOR of a step can touch
     // where this lane's results go: register r = row c_lo = MM::row(kq, r) of column c_hi
     uint32_t ooff[4], osg[4];
     bool ook[4];
@@ -1066,8 +1089,10 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
     auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's pieces
 #pragma unroll
         for (int m = 0; m < PPT; ++m) {
-            const uint4 xl = reinterpret_cast<const uint4*>(p.left + item * p.left_stride)[tid + m * THREADS];
-            const uint4 xr = reinterpret_cast<const uint4*>(p.right + item * p.right_stride)[tid + m * THREADS];
+            uint32_t o = uint32_t(tid + m * THREADS) * 16u;   // (uniform row base) + (32-bit lane offset), see the stores
+            asm volatile("" : "+v"(o));
+            const uint4 xl = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + o);
+            const uint4 xr = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.right + item * p.right_stride) + o);
             __builtin_memcpy(&pf_l[m * CPP], &xl, 16);
             __builtin_memcpy(&pf_r[m * CPP], &xr, 16);
         }
@@ -1077,8 +1102,8 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         for (int e = 0; e < 4; ++e) {
             const int idx = ((e / CPP) * THREADS + tid) * CPP + (e % CPP);   // component of the row
             const uint32_t ml = p.left_map[idx], mr = p.right_map[idx];
-            wa[e] = ((ml >> 16) & 0x7fffu) << ES;
-            wb[e] = (((mr >> 16) & 0x7fffu) + uint32_t(2 * N)) << ES;
+            wa[e] = A_BASE + (((ml >> 16) & 0x7fffu) << ES);
+            wb[e] = B_BASE + (((mr >> 16) & 0x7fffu) << ES);
             sa[e] = ml & 0x80000000u;
             sb[e] = mr & 0x80000000u;
         }
@@ -1091,40 +1116,41 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 T yl = pf_l[e], yr = pf_r[e];
-#if !GAAST_DENSE_NO_CANON
-                if (p.canon_left) yl = T(0) + yl;    // the reference's zero-init + add_grades_from copy: 0.0 + x
-                if (p.canon_right) yr = T(0) + yr;
-#endif
-                yl = MM::flip(yl, sa[e]);
-                yr = MM::flip(yr, sb[e]);
+                if (p.left_signs) yl = MM::flip(yl, sa[e]);   // (uniform) folded sign arms / a permuted basis; the B side always
+                yr = MM::flip(yr, sb[e]);                     // carries the b_hi part of (-1)^(|a_hi| |b_lo|)
                 *(lds_t*)(lds + wa[e]) = yl;
-                *(lds_t*)(lds + wa[e] + NEG) = -yl;
+                *(lds_t*)(lds + wa[e] + NEG_A) = -yl;
                 *(lds_t*)(lds + wb[e]) = yr;
                 *(lds_t*)(lds + wb[e] + NEG) = -yr;
             }
             lds_barrier<THREADS>();
-            if (item + gridDim.x < p.batch) fetch(item + gridDim.x);   // in flight during the products below
+            // in flight during the products below.  Unconditional (the last item re-reads itself): the loop then issues a
+            // KNOWN number of loads and stores per item, and the wait at its top is a counted one
+            fetch(item + gridDim.x < p.batch ? item + gridDim.x : item);
         } else {
             if (!p.left_full || !p.right_full) {
-                for (int e = tid; e < 4 * N; e += THREADS) smem[e] = T(0);
+                for (int e = tid; e < 4 * N + PAD_A; e += THREADS) smem[e] = T(0);
                 lds_barrier<THREADS>();
             }
             stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, 1, tid);
+                                       p.canon_left, smem + A_EL, item_stride, 1, tid);
             stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + 2 * N, item_stride, 1, tid);
+                                       p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid);
             lds_barrier<THREADS>();
-            for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images
-                const int src = e < N ? e : e + N;
-                smem[src + N] = -smem[src];
+            for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images: -B N further, -A N + PAD_A further
+                if (e < N) smem[B_EL + N + e] = -smem[B_EL + e];
+                else smem[A_EL + PAD_A + e] = -smem[A_EL + e - N];
             }
             lds_barrier<THREADS>();
         }
 
         typename MM::acc_t acc = {T(0), T(0), T(0), T(0)};
-        // one step: the lane's four B words and four A words (one LDS read each), four MFMAs
-        auto step = [&](int a_hi, uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff) {
-            T av[4], bv[4];
+        // One step = the lane's four B words and four A words (one LDS read each; f32: the B words as one quad) and four
+        // MFMAs.  The reads are SOFTWARE-PIPELINED: the operands of step a_hi + 1 are requested before the MFMAs of step
+        // a_hi are issued, into a second register set, so that an MFMA never waits for a read issued right before it
+        // (tools/microbench/mfma_operand_regs.hip: with counted waits both operands of EVERY instruction can come from
+        // LDS at 97 % of the pure matrix rate; with a wait for the step's own reads the same stream runs at 77 %).
+        auto load_ops = [&](uint32_t sxs, uint32_t zero, const uint32_t (&abase)[4], int joff, T (&av)[4], T (&bv)[4]) {
             if constexpr (MM::QUAD) {
                 uint32_t addr = bk[0] ^ sxs;
                 if (DEGENERATE) addr = zero ? zero_block : addr;
@@ -1141,20 +1167,30 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                     av[s] = *(const lds_t*)(lds + abase[s] + uint32_t(joff << BS));
                 }
             }
+        };
+        auto mma_ops = [&](const T (&av)[4], const T (&bv)[4]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = MM::mma(av[s], bv[s], acc);
-            asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
         };
+        T av[2][4], bv[2][4];
         if constexpr (SW == 1) {
             // n = 8, 9: all steps unrolled -- every address of a step is a lane constant the compiler keeps across items
+            auto sx_of = [&](int a_hi) -> uint32_t {
+                const uint32_t sx = (uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES));
+                return sx | (((sign_bits[0] >> a_hi) & 1u) ? NEG : 0u);
+            };
+            load_ops(sx_of(0), zero_bits[0] & 1u, ak, 0, av[0], bv[0]);
 #pragma unroll
             for (int a_hi = 0; a_hi < H; ++a_hi) {
-                const uint32_t sx = (uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES));
-                step(a_hi, sx | (((sign_bits[0] >> a_hi) & 1u) ? NEG : 0u), (zero_bits[0] >> a_hi) & 1u, ak, a_hi);
+                if (a_hi + 1 < H) load_ops(sx_of(a_hi + 1), (zero_bits[0] >> (a_hi + 1)) & 1u, ak, a_hi + 1, av[(a_hi + 1) & 1], bv[(a_hi + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // the reads of the next step stay ahead of this step's MFMAs
+                mma_ops(av[a_hi & 1], bv[a_hi & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // n >= 10: 32 steps per pass of a rolled outer loop; the step bits of the current pass sit in word 0 and the
-            // words rotate once per pass (register indices stay compile-time, the body stays 32 steps long whatever n is)
+            // words rotate once per pass (register indices stay compile-time, the body stays 32 steps long whatever n is).
+            // The last step of a pass requests the operands of the next pass's first step (word 1, the next 32 blocks).
             uint32_t sw[SW], zw[SW], aw_base[4];
 #pragma unroll
             for (int w = 0; w < SW; ++w) {
@@ -1163,14 +1199,24 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) aw_base[s] = ak[s];
+            auto sx_of = [&](int w, int j, uint32_t sbits) -> uint32_t {
+                const int a_hi = 32 * w + j;
+                uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES)));
+                asm("" : "+s"(sx));   // whole, in a scalar register
+                return sx | (((sbits >> j) & 1u) << (n + ES));   // NEG = 2^(n + ES) bytes
+            };
+            load_ops(sx_of(0, 0, sw[0]), zw[0] & 1u, aw_base, 0, av[0], bv[0]);
 #pragma unroll 1
             for (int w = 0; w < SW; ++w) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
-                    const int a_hi = 32 * w + j;
-                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << BS) | (MM::QUAD ? uint32_t(((a_hi >> 2) & 1) << 1) << 4 : uint32_t((a_hi >> 1) & 7) << (1 + ES)));
-                    asm("" : "+s"(sx));   // whole, in a scalar register
-                    step(a_hi, sx | (((sw[0] >> j) & 1u) << (n + ES)), (zw[0] >> j) & 1u, aw_base, j);   // NEG = 2^(n + ES) bytes
+                    if (j + 1 < 32)
+                        load_ops(sx_of(w, j + 1, sw[0]), (zw[0] >> (j + 1)) & 1u, aw_base, j + 1, av[(j + 1) & 1], bv[(j + 1) & 1]);
+                    else if (w + 1 < SW)
+                        load_ops(sx_of(w + 1, 0, sw[SW > 1 ? 1 : 0]), zw[SW > 1 ? 1 : 0] & 1u, aw_base, 32, av[0], bv[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_ops(av[j & 1], bv[j & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q + 1 < SW; ++q) {
@@ -1184,12 +1230,30 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
 
         // ---- results -> graded row: (uniform) row base + the lane's byte offsets ----
         unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + item * p.out_stride);
+        if constexpr (MODE == 2) {
+            // every blade produced, nothing accumulated: four unconditional stores.  A reordering sign (permuted basis)
+            // is applied as flip + canonicalisation, so that a zero result stays +0.0 as in the reference (F4)
+            if (p.out_signs) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (ook[r]) {
-                T* q = reinterpret_cast<T*>(orow + ooff[r]);
-                const T v = MM::flip(acc[r], osg[r]);
-                *q = p.beta ? *q + v : v;
+                for (int r = 0; r < 4; ++r) acc[r] = T(0) + MM::flip(acc[r], osg[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (uniform row base) + (32-bit lane offset): the offset is re-defined here so that its zero-extension is not
+                // hoisted out of the item loop as a 64-bit lane constant, which would cost a 64-bit addition per store
+                uint32_t o = ooff[r];
+                asm volatile("" : "+v"(o));
+                *reinterpret_cast<T*>(orow + o) = acc[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ook[r]) {
+                    T* q = reinterpret_cast<T*>(orow + ooff[r]);
+                    T v = MM::flip(acc[r], osg[r]);
+                    if (osg[r] && !p.beta) v = T(0) + v;   // a zero result stays +0.0 under a negated reordering sign
+                    *q = p.beta ? *q + v : v;
+                }
             }
         }
         lds_barrier<THREADS>();   // the images are rewritten by the next item

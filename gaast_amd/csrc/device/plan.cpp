@@ -675,6 +675,8 @@ struct Lowering {
             // every blade produced into a row that holds nothing else: whole rows can be written in 16-byte pieces
             s.out_full = lr.row_len == (int64_t(1) << n);
             for (uint32_t m = 0; m < (1u << n); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
+            for (uint32_t w : s.u32_a) s.left_signs |= int(w >> 31);
+            for (int32_t w : s.i32_a) s.out_signs |= int(w >= 0 && (uint32_t(w) & 0x40000000u));
             const int lo_bits = s.use_mfma ? 5 : 4;
             for (int j = 0; j < n; ++j) {
                 const double g = d.metric_diag[perm[size_t(j)]];

@@ -62,6 +62,7 @@ struct Step {
     int beta = 1;
     int left_full = 0, right_full = 0, out_full = 0;
     int left_contig = 0, right_contig = 0;
+    int left_signs = 0, out_signs = 0;   // DENSE: some left_map word negates / some out_map word carries a reordering sign
     uint32_t neg_hi = 0, zero_hi = 0;
     uint32_t neg_lo = 0;   // lo basis vectors (of the permuted basis) that square to -1
     int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)

@@ -265,12 +265,13 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             // k_gp_mfma16x4<T>: one wave per 16 result columns, one item per workgroup (f64: n = 8 ... 12; f32: build switch)
             s.threads = 64 << (n - 8);
             s.items_per_block = 1;
-            s.lds = size_t(4 * (size_t(1) << n) + 16) * sizeof(T);   // +A, -A, +B, -B images, 16 zeros
+            s.lds = size_t(4 * (size_t(1) << n) + 32) * sizeof(T);   // +B, -B, +A, 16 spare, -A images, 16 zeros
             if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
             using KernD = void (*)(DenseArgs<T>);
-            // [0]: general staging; [1]: register prefetch (full, contiguous, 16-byte aligned rows at launch)
-            auto pick = [&](auto fast_tag) -> KernD {
-                constexpr bool F = decltype(fast_tag)::value;
+            // [0]: general staging; [1]: register prefetch (full, contiguous, 16-byte aligned rows at launch); [2]: ... and
+            // every blade produced, nothing accumulated: straight-line result stores
+            auto pick = [&](auto mode_tag) -> KernD {
+                constexpr int F = decltype(mode_tag)::value;
                 switch (n) {
                 case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, F> : &k_gp_mfma16x4<T, false, 8, F>;
                 case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, F> : &k_gp_mfma16x4<T, false, 9, F>;
@@ -279,11 +280,13 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
                 }
             };
-            const KernD kd = pick(std::false_type{}), kf = pick(std::true_type{});
+            const KernD kd = pick(std::integral_constant<int, 0>{}), kf = pick(std::integral_constant<int, 1>{}),
+                        kw = pick(std::integral_constant<int, 2>{});
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
-            if (int st = allow_lds(s.kern[0], s.lds)) return st;
-            if (int st = allow_lds(s.kern[1], s.lds)) return st;
+            s.kern[2] = reinterpret_cast<const void*>(kw);
+            for (int v = 0; v < 3; ++v)
+                if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
         }
         if (s.use_mfma16) {
@@ -496,8 +499,11 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             blocks = int64_t(g_num_cu) * s.blocks_per_cu;
             if (blocks > groups) blocks = groups;
         }
+        p.left_signs = s.left_signs;
+        p.out_signs = s.out_signs;
         const bool prefetch = s.use_mfma16 && s.kern[1] && p.left_contig && p.right_contig && p.left_full && p.right_full;
-        hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[prefetch ? 1 : 0])), dim3(unsigned(blocks)),
+        const bool whole_rows = prefetch && s.kern[2] && s.out_full && !s.beta;   // k_gp_mfma16x4: straight-line result stores
+        hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[whole_rows ? 2 : prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);
         break;
     }
