@@ -26,7 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
-PEAK_FP64_TFLOPS = 78.6
+PEAK_FP64_TFLOPS = 78.6     # datasheet (64 cycles per v_mfma_f64_16x16x4_f64 at 2.4 GHz); not in the local guide
+MEASURED_FP64_MFMA_TFLOPS = 74.3   # tools/microbench/mfma_f64_rate.hip on this pool (profiles/r03_microbench_mfma_f64_rate.txt)
+SIDE_CONFIGS = ("r8", "cl41", "r12d")   # the other single-GPU BASELINE configurations the default line also times
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 GATHER_WATCHDOG_S = 240     # the multi-GPU gather legs give up after this long (the throughput line is printed regardless)
 GATHER_FAILED_EXIT = 3      # ... and the job then ends with this status: a hung or failed exchange is a FAILED run
@@ -238,6 +240,92 @@ def _traffic_for(workload, batch, kernel_names):
     return ent["bytes"], ent.get("source"), False
 
 
+def roofline_of(wl, workload, spec, batch, kernel_ms, in_len, out_len):
+    """The `roofline` object of one workload: ALGORITHMIC bytes / flops per launch (every input / output component
+    touched once; one multiply + one add per comp-mul entry) over the kernel's average launch duration."""
+    import gaast_amd as ga
+    dtype = wl["dtype"]
+    sz = 4 if dtype == ga.F32 else 8
+    bytes_item = (in_len + out_len) * sz
+    flops_item = wl.get("flops_item", 2 * wl["entries"])
+    launches = spec.launches()
+    dense = any("product_dense" in l or "product_spinor" in l for l in launches)
+    peak_tf = PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS
+    ach_tf = flops_item * batch / (kernel_ms * 1e-3) * 1e-12
+    ach_gb = bytes_item * batch / (kernel_ms * 1e-3) * 1e-9
+    if dense:
+        roof = {"bound": "mfma", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
+                "traffic": None,
+                "note": ("dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); " if dtype == ga.F32 else
+                         "dense product: fp64 vector FMA peak == fp64 MFMA peak (78.6 TFLOP/s datasheet; 74-77 measured: "
+                         "profiles/r03_microbench_mfma_f64_rate.txt); ") +
+                        f"algorithmic HBM {ach_gb:.1f} GB/s = {ach_gb / PEAK_HBM_GBPS:.4f} of 8 TB/s"}
+        if dtype != ga.F32:
+            roof["frac_of_measured_peak"] = ach_tf / MEASURED_FP64_MFMA_TFLOPS
+    else:
+        roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
+                "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
+    roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
+    traffic, source, stale = _traffic_for(workload, batch, [roof["kernel"]])
+    roof["traffic"] = traffic
+    roof["traffic_source"] = source
+    roof["traffic_stale"] = stale
+    roof["algorithmic_bytes_per_launch"] = bytes_item * batch
+    roof["kernel_ms"] = kernel_ms
+    roof["flops_per_item"] = flops_item
+    roof["bytes_per_item"] = bytes_item
+    return roof
+
+
+def side_config(name, dev, stream, steps, warmup):
+    """One of the other single-GPU BASELINE configurations, measured in the same process after the headline: the same
+    timing discipline (inputs resident, HIP events on the launch stream around every step), a few steps."""
+    import torch
+    import gaast_amd as ga
+    wl = workload_spec(name)
+    n, dtype, batch = wl["n"], wl["dtype"], wl["default_batch"]
+    tdt = torch.float32 if dtype == ga.F32 else torch.float64
+    exprs = [ga.mv(ga.Input(s, g, n)) for s, g in enumerate(wl["inputs"])]
+    t0 = time.time()
+    spec = wl["build"](*exprs).specialize(ga.MetricAlgebra(wl["metric"]), dtype=dtype, flags=wl.get("flags", 0))
+    spec.program()
+    t_spec = time.time() - t0
+    out_mask, out_len = spec.output_info()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    ins, in_t = [], []
+    for slot, g in enumerate(wl["inputs"]):
+        rl = ga.graded.row_len(n, ga.graded._mask_of(g))
+        nb = 1 if slot in wl.get("shared", []) else batch
+        t = torch.empty((nb, rl), device=dev, dtype=tdt)
+        for lo in range(0, nb, 1 << 16):
+            t[lo:lo + (1 << 16)].uniform_(-1, 1, generator=gen)
+        in_t.append(t)
+        ins.append(ga.DeviceMV.wrap_tensor(t, n, g))
+    out_t = torch.empty((batch, out_len), device=dev, dtype=tdt)
+    out = ga.DeviceMV.wrap_tensor(out_t, n, ga.GradeSet(out_mask))
+    for _ in range(warmup):
+        spec.eval_batch(ins, batch, out=out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        spec.eval_batch(ins, batch, out=out)
+        e1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
+    in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)
+    res = {"workload": wl["label"], "key": name, "dim": n, "dtype": wl["dtname"], "batch": batch, "steps": steps, "warmup": warmup,
+           "value": batch * steps / wall, "unit": "products/s" if len(wl["inputs"]) == 2 and wl["entries"] == 4 ** n else "evaluations/s",
+           "ms_per_step": wall / steps * 1e3, "launches_per_eval": spec.launches(), "specialize_s": t_spec,
+           "roofline": roofline_of(wl, name, spec, batch, kernel_ms, in_len, out_len)}
+    del ins, in_t, out, out_t, spec
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +339,8 @@ def main():
     ap.add_argument("--gather-chunks", type=int, default=4)
     ap.add_argument("--no-alt", action="store_true", help="skip the opt-in matrix-representation side measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-item latency side measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configurations (r8, cl41, r12d) "
+                    "the default line also times")
     ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="extra GAAST_FLAG_* bits for the program (A/B measurements)")
     args = ap.parse_args()
 
@@ -498,38 +588,23 @@ def main():
                    "note": "one gaast_hip_eval of one input set + synchronize (the reference evaluates one input set per "
                            "eval()); the program is built once per SpecializedAst"}
 
+    # the other single-GPU BASELINE configurations (configs[1] R^8 f32, configs[4] R^{4,1} sandwich f64, and R^12 in the
+    # reference's value type), each with its own roofline object: a few steps each, after the headline's buffers are idle
+    side = []
+    if args.workload == "r12" and rank == 0 and world == 1 and not args.no_configs and not args.batch and not args.flags:
+        for name in SIDE_CONFIGS:
+            try:
+                side.append(side_config(name, dev, stream, steps=10, warmup=3))
+            except Exception as e:      # never at the expense of the headline line
+                side.append({"key": name, "error": f"{type(e).__name__}: {e}"})
+
     def emit(gather):
         """rank 0: the ONE JSON line"""
         items_total = global_batch * args.steps
         value = items_total / wall
-        sz = 4 if dtype == ga.F32 else 8
         in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)      # shared inputs are read once, not per item
-        bytes_item = (in_len + out_len) * sz          # every input/output component touched once
-        # one multiply + one add per comp-mul entry (the matrix-representation kernel: what it executes)
-        flops_item = wl.get("flops_item", 2 * wl["entries"])
         launches = spec.launches()
-        dense = any("product_dense" in l or "product_spinor" in l for l in launches)
-        peak_tf = PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS
-        ach_tf = flops_item * batch / (kernel_ms * 1e-3) * 1e-12
-        ach_gb = bytes_item * batch / (kernel_ms * 1e-3) * 1e-9
-        if dense:
-            roof = {"bound": "mfma", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
-                    "traffic": None,
-                    "note": ("dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); " if dtype == ga.F32 else
-                             "dense product: fp64 vector FMA peak == fp64 MFMA peak (78.6 TFLOP/s); ") +
-                            f"algorithmic HBM {ach_gb:.1f} GB/s = {ach_gb / PEAK_HBM_GBPS:.4f} of 8 TB/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
-                    "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
-        roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
-        traffic, source, stale = _traffic_for(args.workload, batch, [roof["kernel"]])
-        roof["traffic"] = traffic
-        roof["traffic_source"] = source
-        roof["traffic_stale"] = stale
-        roof["algorithmic_bytes_per_launch"] = bytes_item * batch
-        roof["kernel_ms"] = kernel_ms
-        roof["flops_per_item"] = flops_item
-        roof["bytes_per_item"] = bytes_item
+        roof = roofline_of(wl, args.workload, spec, batch, kernel_ms, in_len, out_len)
         res = {
             "metric": "full-MV geometric products/sec (dim n); achieved HBM GB/s vs roofline",
             "value": value, "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -542,6 +617,8 @@ def main():
                        "shards": counts, "launches_per_eval": launches, "specialize_s": t_spec},
             "roofline": roof,
         }
+        if side:
+            res["configs"] = side
         if alt is not None:
             res["matrix_representation"] = alt
         if latency is not None:

@@ -3,27 +3,6 @@
 #pragma once
 #include "kernels_common.hip.hpp"
 
-// build-time A/B switches of the matrix-core kernels (defaults = the measured best)
-#ifndef GAAST_MFMA32_DPP
-#define GAAST_MFMA32_DPP 0
-#endif
-#ifndef GAAST_MFMA32_LEAN      /* k_gp_mfma32: B addresses as (lane constant) ^ (step constant), block sign in three instructions */
-#define GAAST_MFMA32_LEAN 1
-#endif
-#ifndef GAAST_DENSE_NO_CANON
-#define GAAST_DENSE_NO_CANON 0
-#endif
-#ifndef GAAST_MFMA16_SETPRIO
-#define GAAST_MFMA16_SETPRIO 1
-#endif
-#ifndef GAAST_MFMA16_PRIO_RAMP
-#define GAAST_MFMA16_PRIO_RAMP 0
-#endif
-#ifndef GAAST_SLOT_PRIO        /* persistent matrix-core kernels: a fixed, different priority per wave slot of a SIMD */
-#define GAAST_SLOT_PRIO 0
-#endif
-#define GAAST_STR2(x) #x
-#define GAAST_STR(x) GAAST_STR2(x)
 
 namespace gaast {
 
@@ -71,7 +50,6 @@ struct DenseArgs {
     uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
     uint32_t neg_lo;            // lo basis vectors that square to -1
     int beta;
-    int out_rows;               // k_gp_mfma16: every blade is produced into 16-byte aligned rows of 2^n words, beta = 0
     int left_signs;             // some left_map word has its negate bit set (folded sign arms, permuted basis)
     int out_signs;              // some out_map word has its sign bit set (permuted basis)
     int64_t batch;
@@ -408,21 +386,6 @@ __device__ __forceinline__ constexpr int lo5_reorder_parity(int a, int b) {
     return par;
 }
 
-// DPP lane permutations inside a row of 16 lanes (one item's lanes): lane i reads lane i ^ e.  quad_perm gives
-// e = 1, 2, 3, row_half_mirror e = 7, row_mirror e = 15; every e in 0..15 is (0 | 4 | 8 | 12) ^ (0..3).
-constexpr int DPP_QX1 = 0xB1, DPP_QX2 = 0x4E, DPP_QX3 = 0x1B, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_row(uint32_t v) {
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, true));
-}
-template <int E>
-__device__ __forceinline__ uint32_t dpp_quad_xor(uint32_t v) {   // lane i <- lane i ^ E, E in 0..3
-    if constexpr (E == 0) return v;
-    else if constexpr (E == 1) return dpp_row<DPP_QX1>(v);
-    else if constexpr (E == 2) return dpp_row<DPP_QX2>(v);
-    else return dpp_row<DPP_QX3>(v);
-}
-
 // LDS position of blade m inside the B image: block x = m >> 5; inside it the components are
 // de-interleaved by the parity of k = m & 31 (even k first), 8 quads rotated by (x >> 1) & 7.
 __device__ __forceinline__ int mfma_b_pos(int m) {
@@ -467,78 +430,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         const int i = lane & 31, h = lane >> 5;
         const int c_hi = (tile << 5) | i;
 
-#if GAAST_MFMA32_DPP
-        // The A operand of lane (h, i) for term s2 is +-A[a_hi][i ^ k], k = 2 s2 + h.  The lane reads TWO words of the
-        // block once per step, A[i ^ h] and A[i ^ h ^ 16], and the lanes of a 16-lane row exchange them through DPP:
-        // A[i ^ (2 s2 + h)] is what lane (h, i ^ (2 s2 & 15)) read first (s2 < 8) or second (s2 >= 8) -- no LDS gather
-        // and no address arithmetic per term.  amask[s2]: sign of that operand, a lane constant.
-        uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int k = 2 * s2 + h;
-            const int a_lo = i ^ k;
-            int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
-            for (int pp = 1; pp < 5; ++pp)
-                if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-            amask[s2] = uint32_t(par) << 31;
-        }
-        const uint32_t* As_own0 = reinterpret_cast<const uint32_t*>(As) + (i ^ h);
-        const uint32_t* As_own1 = reinterpret_cast<const uint32_t*>(As) + (i ^ h ^ 16);
-
-        // one accumulator chain per wave: a dependent f32 MFMA issues back to back; bitwise vector instructions issue
-        // beside the chain (tools/microbench/mfma16_loop.hip), LDS -> VGPR operand reads cost matrix-pipe time
-        // (tools/microbench/mfma_rate.hip)
-        float16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-        auto one_step = [&](int a_hi) {
-            // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
-            uint32_t sp = uint32_t(a_hi) >> 1;
-            sp ^= sp >> 1;
-            sp ^= sp >> 2;
-            sp ^= sp >> 4;
-            sp ^= sp >> 8;
-            const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-            const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
-                                __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-            const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
-            uint32_t keep = 0xffffffffu;
-            if (DEGENERATE) {
-                if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) keep = 0u;
-            }
-            const int x = a_hi ^ c_hi;
-            const int rot = (x >> 1) & 7;
-            const uint4* bp = reinterpret_cast<const uint4*>(Bs + (x << 5));
-            uint32_t bv[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = bp[((h << 2) | q) ^ rot];
-                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
-            }
-            const uint32_t v0 = As_own0[a_hi << 5], v1 = As_own1[a_hi << 5];
-            // lane i <- lane i ^ e for e = 4, 8, 12 (e = 2 and the combinations ride on the xor itself)
-            const uint32_t t7a = dpp_row<DPP_ROW_HALF_MIRROR>(v0), t15a = dpp_row<DPP_ROW_MIRROR>(v0);
-            const uint32_t a4 = dpp_row<DPP_QX3>(t7a), a8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15a), a12 = dpp_row<DPP_QX3>(t15a);
-            const uint32_t t7b = dpp_row<DPP_ROW_HALF_MIRROR>(v1), t15b = dpp_row<DPP_ROW_MIRROR>(v1);
-            const uint32_t b4 = dpp_row<DPP_QX3>(t7b), b8 = dpp_row<DPP_ROW_HALF_MIRROR>(t15b), b12 = dpp_row<DPP_QX3>(t15b);
-            auto term = [&](auto stag, uint32_t base) {
-                constexpr int s2 = decltype(stag)::value;   // lane exchange distance (2 s2) & 15 = base distance ^ (0 | 2)
-                const float a = __uint_as_float(dpp_quad_xor<((2 * s2) & 3)>(base) ^ amask[s2]);
-                uint32_t b = bv[s2] ^ bmask;
-                if (DEGENERATE) b &= keep;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(b), acc, 0, 0, 0);
-            };
-            term(std::integral_constant<int, 0>{}, v0);   term(std::integral_constant<int, 1>{}, v0);
-            term(std::integral_constant<int, 2>{}, a4);   term(std::integral_constant<int, 3>{}, a4);
-            term(std::integral_constant<int, 4>{}, a8);   term(std::integral_constant<int, 5>{}, a8);
-            term(std::integral_constant<int, 6>{}, a12);  term(std::integral_constant<int, 7>{}, a12);
-            term(std::integral_constant<int, 8>{}, v1);   term(std::integral_constant<int, 9>{}, v1);
-            term(std::integral_constant<int, 10>{}, b4);  term(std::integral_constant<int, 11>{}, b4);
-            term(std::integral_constant<int, 12>{}, b8);  term(std::integral_constant<int, 13>{}, b8);
-            term(std::integral_constant<int, 14>{}, b12); term(std::integral_constant<int, 15>{}, b12);
-        };
-#else
         // lane constants: sign masks of the A operand for both parities of |a_hi|, and the
         // byte offset of A[i ^ k] inside a block, for k = 2s + h
         uint32_t amask[16];   // for |a_hi| even; flipped in place to the odd-parity pattern between the passes
@@ -563,7 +454,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         const unsigned char* As_b = reinterpret_cast<const unsigned char*>(As);
-#if GAAST_MFMA32_LEAN
         // lane constants of the B side: byte offset of logical quad q of the lane's block, (lane constant) ^ (step constant)
         // as in k_gp_mfma16; c_hi with a spare bit set, so that the uniform part u of the block sign rides in the popcount
         const unsigned char* Bs_b = reinterpret_cast<const unsigned char*>(Bs);
@@ -571,7 +461,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = (uint32_t(c_hi) << 7) | (uint32_t((((h << 2) | q) ^ (c_hi >> 1)) & 7) << 4);
         const uint32_t c_hi_u = uint32_t(c_hi) | 0x8000u;
-#endif
         auto one_step = [&](int a_hi) {
             // block sign: wave-uniform part on the scalar unit, lane part = and + popcount
             uint32_t sp = uint32_t(a_hi) >> 1;
@@ -582,33 +471,18 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
             const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
             const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^
                                 __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-#if GAAST_MFMA32_LEAN
             const uint32_t bmask = uint32_t(__builtin_popcount(c_hi_u & (M | (u << 15)))) << 31;
-#else
-            const uint32_t bmask = ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << 31;
-#endif
             float bscale = 1.f;
             if (DEGENERATE) {
                 if (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) bscale = 0.f;
             }
             float bv[16];
-#if GAAST_MFMA32_LEAN
             const uint32_t sx = (uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4v v = *reinterpret_cast<const float4v*>(Bs_b + (bq[q] ^ sx));
                 bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
             }
-#else
-            const int x = a_hi ^ c_hi;
-            const int rot = (x >> 1) & 7;
-            const float4v* bp = reinterpret_cast<const float4v*>(Bs + (x << 5));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4v v = bp[((h << 2) | q) ^ rot];
-                bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
-            }
-#endif
             const uint32_t abase = uint32_t(a_hi) << 7;
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
@@ -619,7 +493,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
         };
-#endif
         const int half = H >> 1;
         for (int t2 = 0; t2 < half; ++t2) one_step((t2 << 1) | (__builtin_popcount(uint32_t(t2)) & 1));
 #pragma unroll
@@ -636,18 +509,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
             store_result<float>(orow, om[c_lo], acc[r], p.beta);
         }
     }
-}
-
-// Waves that share a SIMD start a persistent kernel together and, being identical, stay in phase: they stage their
-// operands at the same time (matrix pipe idle) and then compete for the pipe.  A fixed, DIFFERENT priority per wave slot
-// of the SIMD (HW_ID[3:0]) lets one wave run ahead until the phases alternate.
-__device__ __forceinline__ void wave_slot_priority() {
-#if GAAST_SLOT_PRIO
-    const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // hwreg(HW_REG_HW_ID, 0, 4)
-    if (slot == 0) __builtin_amdgcn_s_setprio(3);
-    else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-    else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-#endif
 }
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and
@@ -712,7 +573,6 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
     const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full;
-    wave_slot_priority();
 
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
 
@@ -819,9 +679,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t w = mw[side][4 * m + c];
                             float y = x[c];
-#if !GAAST_DENSE_NO_CANON
                             if (side ? p.canon_right : p.canon_left) y = 0.f + y;   // the reference's zero-init + add_grades_from copy
-#endif
                             const uint32_t yb = __float_as_uint(y) ^ (w & 0x80000000u);
                             const uint32_t at = uint32_t(k) * uint32_t(item_stride * 4) + (side ? 2u * NEG : 0u) + (((w >> 16) & 0x7fffu) << 2);
                             *(__attribute__((address_space(3))) uint32_t*)(lds + at) = yb;
@@ -879,7 +737,77 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
                 asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
             };
-            if constexpr (SIGN_WORDS > 0) {
+            if constexpr (SIGN_WORDS > 0 && NDIM <= 11) {
+                // block signs from the per-launch bit masks: two vector instructions per step (bit, address bit) instead
+                // of five; chunks of 16 steps (the A addresses move once per chunk).
+                // The operand reads are SOFTWARE-PIPELINED over the linear sequence of MFMAs m = 16 step + t: the A word of
+                // MFMA m + 3 and the B quad after the current one are requested before MFMA m is issued, so that no MFMA
+                // waits for a read issued right before it (round 2's loop did: with two waves per SIMD the matrix pipe
+                // idled for the part of the LDS latency the other wave's 64-cycle MFMA does not cover -- 89.8 % busy;
+                // tools/microbench/mfma_operand_regs.hip: with counted waits every operand can come from LDS at 97 % of
+                // the pure matrix rate).  A words rotate through 4 registers, B quads through 2 x 4.
+                uint32_t awin[4];
+                uint4v qb[2];
+                auto b_quad = [&](int a_hi, int q, uint32_t sxs) -> uint4v {
+                    uint32_t addr = b_base + (bq[q] ^ sxs);
+                    if (DEGENERATE) addr = (uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? zero_block : addr;
+                    return *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
+                };
+                auto a_word = [&](int t, int j) -> uint32_t {   // word t of step j of the current chunk (j = 16: the next chunk's first)
+                    return ABS_A ? *(__attribute__((address_space(3))) const uint32_t*)size_t(ak[t] + uint32_t(j << 7))
+                                 : *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(j << 7));
+                };
+                auto sx_of = [&](int a_hi) -> uint32_t {
+                    // (wave-uniform: kept on the scalar unit, one v_lshl_or_b32 joins it with the lane's sign bit)
+                    uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t(a_hi) << 7) | (uint32_t((a_hi >> 1) & 7) << 4));
+                    asm("" : "+s"(sx));   // whole, in a scalar register: otherwise its parts are OR-ed in one by one on the vector unit
+                    return sx;
+                };
+                // prologue: the first three A words and the first B quad of step 0
+                uint32_t sxs = ((sgn[0] & 1u) << (n + 2)) | sx_of(0);   // the current step's; computed once, one step ahead
+                qb[0] = b_quad(0, 0, sxs);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) awin[t] = a_word(t, 0);
+#pragma unroll
+                for (int w = 0; w < SIGN_WORDS; ++w) {
+                    uint32_t sw = sgn[w];
+                    const uint32_t next_word_bit0 = w + 1 < SIGN_WORDS ? (sgn[w + 1 < SIGN_WORDS ? w + 1 : w] & 1u) : 0u;
+#pragma unroll 1
+                    for (int c = 0; c < 2; ++c) {
+                        const int a0 = 32 * w + 16 * c;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int a_hi = a0 + j;
+                            // sign bit of the NEXT step: bit j + 1 of the chunk's bits; past the word: the next word's bit 0
+                            const uint32_t nbit = j < 15 ? (sw >> (j + 1)) & 1u : (c == 0 ? (sw >> 16) & 1u : next_word_bit0);
+                            const uint32_t nsxs = (nbit << (n + 2)) | sx_of(a_hi + 1);
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) {
+                                const int m = 16 * j + t;                    // position in the chunk's MFMA sequence
+                                // requests: A word of MFMA m + 3; at the first MFMA of a quad, the following quad
+                                const int t3 = (t + 3) & 15, j3 = j + ((t + 3) >> 4);
+                                awin[(m + 3) & 3] = a_word(t3, j3);
+                                if ((t & 3) == 0) {
+                                    const int q = t >> 2;
+                                    qb[(q + 1) & 1] = q < 3 ? b_quad(a_hi, q + 1, sxs) : b_quad(a_hi + 1, 0, nsxs);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                const uint4v bqv = qb[(t >> 2) & 1];
+                                const uint32_t bwv = (t & 3) == 0 ? bqv.x : (t & 3) == 1 ? bqv.y : (t & 3) == 2 ? bqv.z : bqv.w;
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(awin[m & 3]), __uint_as_float(bwv), acc, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            sxs = nsxs;
+                        }
+                        sw >>= 16;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) ak[t] += 16u << 7;
+                    }
+                }
+            } else if constexpr (SIGN_WORDS > 0) {
+                // n = 12: round 2's loop (every read in its step); the pipelined form measures 1 % SLOWER there (15.65 -> 15.83 ms,
+                // same box, tools/ab_r3a.sh) while n = 10 / 11 gain 6.5 / 3.7 % -- at n = 12 the other wave of the SIMD already
+                // covers the read latency and the extra bookkeeping of the pipeline costs more than it hides
                 // block signs from the per-launch bit masks: two vector instructions per step (bit, address bit) instead
                 // of five; chunks of 16 steps (the A addresses move once per chunk)
 #pragma unroll
@@ -1257,260 +1185,6 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
             }
         }
         lds_barrier<THREADS>();   // the images are rewritten by the next item
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Matrix-core form for n = 8, 9 (f32): v_mfma_f32_16x16x1_4b_f32, four independent 16 x 16 outer products
-// per instruction.  With lo = 4 bits the contribution of block a_hi to the 16 result columns c_hi of a tile is
-// a 16 x 16 x 16 GEMM per ITEM; the four blocks of the instruction are four items, so one wave owns all
-// 16 x 16 results (n = 8; half of them at n = 9) of four items:
-//   lane 16 b + i:  A operand = +-A_b[a_hi][i ^ k]          (lane-constant position and sign per term k)
-//                   B operand = +-B_b[a_hi ^ c_hi(i)][k]    (the lane's block; sign per lane and step)
-//   16 instructions (one per k) per step.  Same sums as k_gp_mfma32 / k_gp_dense: a k-ordered fmaf chain.
-//
-// On this chip every vector instruction of a resident wave costs the SIMD ~4.8 cycles the f32 matrix pipe does not get
-// (tools/microbench/mfma16_loop2.hip), LDS reads do not.  So NO sign is applied with vector instructions: each item keeps
-// FOUR images in LDS, +A, -A, +B, -B, and every sign is an ADDRESS:
-//   * A operand of term k: one ds_read_b32 at (lane constant of k) + 64 a_hi -- the constant points into +A or -A by the
-//     lane-constant sign of (i, k) (reordering sign of the lo bits, lo vectors that square to -1);
-//   * B operand: the lane's block from +B or -B by the block sign of (a_hi, c_hi): one address bit per step.
-//   The remaining factor (-1)^(|a_hi| |k|) is split with |a_hi| = |b_hi| + |c_hi| (mod 2): the b_hi part is folded
-//   into the B images while staging (host map), the c_hi part is a lane constant of the odd-|k| words: the words of a
-//   block are stored even-|k| first (two 16-byte quads), odd-|k| last, and lanes with odd |c_hi| read the odd quads
-//   from the image of the other sign.
-// Per step of 16 MFMAs: 16 ds_read_b32 + 4 ds_read_b128 and six vector instructions (the B addresses).
-// Operand images: A in plain blade order; B blocks of 16 words in the order above, the four quads of block x rotated by
-// (x >> 2) & 3 (16 lanes reading 16 blocks: 16 different bank quads); items are 4 * 2^n + 16 words apart, the 16 spare
-// words stay zero (the B "block" of a vanishing contribution, degenerate metrics).
-// ------------------------------------------------------------------------------------------
-// One workgroup = ONE group of four items (n = 8: a single wave, n = 9: two waves), persistent: no synchronisation
-// between the groups a CU works on, their staging / product / store phases drift apart and fill each other's stalls.
-// FAST: both operands hold every blade in consecutive, 16-byte aligned rows (the host checks): the rows of the next group
-// are fetched into registers while the matrix cores work on the current one.  Otherwise: the general staging of
-// stage_operands (partial grade sets, strided / unaligned rows).
-template <bool DEGENERATE, int NDIM, bool FAST>
-__global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_gp_mfma16(DenseArgs<float> p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* smem = reinterpret_cast<float*>(smem_raw);
-    lds_u8* lds = (lds_u8*)smem_raw;
-    constexpr int n = NDIM;                       // 8 or 9
-    constexpr int N = 1 << n;
-    constexpr int H = 1 << (n - 4);               // number of 16-blocks
-    constexpr int THREADS = 64 << (n - 8);        // one wave per 16 result columns
-    constexpr int IPB = 4;                        // items per workgroup pass: the four blocks of the instruction
-    constexpr int item_stride = 4 * N + 16;       // words: +A, -A, +B, -B images, 16 zero words
-    constexpr uint32_t NEG = uint32_t(N) * 4u;    // bytes from an image to its negated copy (one address bit)
-    constexpr uint32_t ITEM_BYTES = uint32_t(item_stride) * 4u;
-    constexpr int COUNT4 = N / 4;                 // 16-byte pieces of a full row == THREADS: thread t moves piece t of every row
-    static_assert(COUNT4 == THREADS, "one 16-byte piece of each row per thread");
-    const int tid = threadIdx.x;
-    const int64_t num_groups = (p.batch + IPB - 1) / IPB;
-    wave_slot_priority();
-
-    // the 16 spare words of every item: zero for the whole launch
-    if (tid < 16 * IPB) smem[(tid >> 4) * item_stride + 4 * N + (tid & 15)] = 0.f;
-
-    // byte address of each of the thread's 4 + 4 components inside item 0's +A / +B images (item k is a compile-time
-    // distance away), and their negate bits
-    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    if (FAST) {
-        const uint4 ml = reinterpret_cast<const uint4*>(p.left_map)[tid], mr = reinterpret_cast<const uint4*>(p.right_map)[tid];
-        const uint32_t mls[4] = {ml.x, ml.y, ml.z, ml.w}, mrs[4] = {mr.x, mr.y, mr.z, mr.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            wa[c] = ((mls[c] >> 16) & 0x7fffu) << 2;
-            wb[c] = (((mrs[c] >> 16) & 0x7fffu) + uint32_t(2 * N)) << 2;
-            sa[c] = mls[c] & 0x80000000u;     // a folded Negation / Reverse / GradeInvolution, the basis permutation's sign,
-            sb[c] = mrs[c] & 0x80000000u;     // (B) the (-1)^(|b_hi| |k|) of the image
-        }
-    }
-    float4 pf_l[IPB], pf_r[IPB];
-    auto fetch = [&](int64_t g) {
-        const int64_t it0 = g * IPB;
-        const int cnt = int(p.batch - it0 < IPB ? p.batch - it0 : IPB);
-#pragma unroll
-        for (int k = 0; k < IPB; ++k) {
-            if (k < cnt) {   // (uniform) row base + the thread's piece
-                pf_l[k] = reinterpret_cast<const float4*>(p.left + (it0 + k) * p.left_stride)[tid];
-                pf_r[k] = reinterpret_cast<const float4*>(p.right + (it0 + k) * p.right_stride)[tid];
-            }
-        }
-    };
-    auto scatter4 = [&](int k, const float4& v, const uint32_t (&w)[4], const uint32_t (&sg)[4], int canon) {
-        const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float y = x[c];
-#if !GAAST_DENSE_NO_CANON
-            if (canon) y = 0.f + y;           // the reference's zero-init + add_grades_from copy: 0.0 + x
-#endif
-            const uint32_t yb = __float_as_uint(y) ^ sg[c];
-            *(__attribute__((address_space(3))) uint32_t*)(lds + w[c] + uint32_t(k) * ITEM_BYTES) = yb;
-            *(__attribute__((address_space(3))) uint32_t*)(lds + w[c] + uint32_t(k) * ITEM_BYTES + NEG) = yb ^ 0x80000000u;
-        }
-    };
-    if (FAST && int64_t(blockIdx.x) < num_groups) fetch(blockIdx.x);
-
-    const int tile = tid >> 6, lane = tid & 63;   // wave <-> 16 result columns
-    const int blk = lane >> 4, i = lane & 15;     // lane's item of the group (operand side), row / column inside the tile
-    const int c_hi = (tile << 4) | i;
-
-    // A operand of term t (k = mfma16_k(t)): +-A[a_hi][i ^ k], sign a lane constant (reordering sign of the lo bits, lo
-    // vectors that square to -1): byte address inside the item's +A / -A pair, without the step's 64 a_hi
-    uint32_t ak[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int k = mfma16_k(t);
-        const int a_lo = i ^ k;
-        int par = __builtin_popcount(uint32_t(a_lo & k) & p.neg_lo) & 1;   // lo vectors that square to -1
-        for (int pp = 1; pp < 4; ++pp)
-            if ((a_lo >> pp) & 1) par ^= __builtin_popcount(k & ((1 << pp) - 1)) & 1;
-        ak[t] = uint32_t(blk) * ITEM_BYTES + (uint32_t(a_lo) << 2) + (par ? NEG : 0u);
-    }
-    // block sign of every step, one bit per a_hi: (-1)^(u(a_hi) + parity(c_hi & M(a_hi))), and (DEGENERATE) the
-    // steps whose contribution to this lane's column vanishes
-    uint32_t sign_bits = 0, zero_bits = 0;
-#pragma unroll 1
-    for (int a_hi = 0; a_hi < H; ++a_hi) {
-        uint32_t sp = uint32_t(a_hi) >> 1;
-        sp ^= sp >> 1;
-        sp ^= sp >> 2;
-        sp ^= sp >> 4;
-        const uint32_t M = sp ^ (uint32_t(a_hi) & p.neg_hi);
-        const uint32_t u = (__builtin_popcount(uint32_t(a_hi) & sp) ^ __builtin_popcount(uint32_t(a_hi) & p.neg_hi)) & 1u;
-        sign_bits |= ((u ^ uint32_t(__builtin_popcount(uint32_t(c_hi) & M))) & 1u) << a_hi;
-        if (DEGENERATE) zero_bits |= ((uint32_t(a_hi) & ~uint32_t(c_hi) & p.zero_hi) ? 1u : 0u) << a_hi;
-    }
-    // B block x = a_hi ^ c_hi, its four 16-byte quads rotated by (x >> 2) & 3 (host: the map's positions): the byte
-    // offset of logical quad q inside the +B / -B pair is (lane constant) ^ (step constant); quads 2, 3 hold the odd-|k|
-    // words, which lanes with odd |c_hi| take from the other image
-    const uint32_t b_base = uint32_t(blk) * ITEM_BYTES + 2u * NEG;
-    const uint32_t zero_block = uint32_t(blk) * ITEM_BYTES + 4u * NEG;
-    uint32_t bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bq[q] = (uint32_t(c_hi) << 6) | (uint32_t((q ^ (c_hi >> 2)) & 3) << 4);
-        if (q >= 2 && (__builtin_popcount(uint32_t(c_hi)) & 1)) bq[q] ^= NEG;
-    }
-    // where this lane's results go: register 4 b + r = item b of the group, c_lo = 4 rg + r, c_hi = tile*16 + (lane & 15):
-    // byte offset in the result row, sign of the basis permutation, "not produced"
-    const int rg = lane >> 4;
-    uint32_t ooff[4], osg[4];
-    bool ook[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int32_t w = p.out_map[(c_hi << 4) + 4 * rg + r];
-        ook[r] = w >= 0;
-        ooff[r] = uint32_t(w & 0x3fffffff) << 2;
-        osg[r] = (uint32_t(w) & 0x40000000u) << 1;
-    }
-
-    for (int64_t g = blockIdx.x; g < num_groups; g += gridDim.x) {
-        const int64_t item0 = g * IPB;
-        const int nitems = int(p.batch - item0 < IPB ? p.batch - item0 : IPB);
-        // ---- both operands of the group's items into their LDS images ----
-        if (FAST) {
-#pragma unroll
-            for (int k = 0; k < IPB; ++k) {
-                if (k < nitems) {
-                    scatter4(k, pf_l[k], wa, sa, p.canon_left);
-                    scatter4(k, pf_r[k], wb, sb, p.canon_right);
-                }
-            }
-        } else {
-            if (!p.left_full || !p.right_full) {
-                for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
-                lds_barrier<THREADS>();
-            }
-            stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                           p.canon_left, smem, item_stride, nitems, tid);
-            stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
-            lds_barrier<THREADS>();
-            for (int e = tid; e < nitems * 2 * N; e += THREADS) {   // the negated images
-                const int sit = e / (2 * N), j = e - sit * (2 * N);
-                const int src = sit * item_stride + (j < N ? j : j + N);
-                smem[src + N] = -smem[src];
-            }
-        }
-        lds_barrier<THREADS>();
-        if (FAST && g + gridDim.x < num_groups) fetch(g + gridDim.x);   // in flight during the products below
-
-        float16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-        // n = 8: the 64 B addresses of a group (16 steps x 4 quads) are lane constants the compiler keeps in registers
-        // (no vector instruction in the loop); n = 9 would need 128: recomputed per group, 6 instructions per step
-        uint32_t sign_now = sign_bits;
-        if (NDIM > 8) asm volatile("" : "+v"(sign_now));
-#if GAAST_MFMA16_SETPRIO && !GAAST_SLOT_PRIO
-        __builtin_amdgcn_s_setprio(2);   // waves in their product phase go first
-#endif
-#pragma unroll
-        for (int a_hi = 0; a_hi < H; ++a_hi) {
-            // the lane's B block, from the image of its block sign
-            const uint32_t sx = (uint32_t(a_hi) << 6) | (uint32_t((a_hi >> 2) & 3) << 4);
-            const uint32_t sxs = sx | (((sign_now >> a_hi) & 1u) ? NEG : 0u);
-            uint32_t bw[16], aw[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t addr = b_base + (bq[q] ^ sxs);
-                if (DEGENERATE) addr = ((zero_bits >> a_hi) & 1u) ? zero_block : addr;
-                const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + addr);
-                bw[4 * q + 0] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                aw[t] = *(__attribute__((address_space(3))) const uint32_t*)(lds + ak[t] + uint32_t(a_hi << 6));
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(aw[t]), __uint_as_float(bw[t]), acc, 0, 0, 0);
-            asm volatile("" ::: "memory");   // keep the LDS reads of a step in their step
-#if GAAST_MFMA16_SETPRIO && GAAST_MFMA16_PRIO_RAMP && !GAAST_SLOT_PRIO
-            if (a_hi == H / 2 - 1) __builtin_amdgcn_s_setprio(3);   // the wave that is ahead stays ahead: co-resident waves drift out of phase
-#endif
-        }
-#if GAAST_MFMA16_SETPRIO && !GAAST_SLOT_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-
-        if (p.out_rows) {
-            // ---- results -> the items' (dead) +A images in result-row order, then whole rows in 16-byte pieces ----
-            lds_barrier<THREADS>();   // every wave is done with the images
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    *(__attribute__((address_space(3))) uint32_t*)(lds + uint32_t(b) * ITEM_BYTES + ooff[r]) =
-                        __float_as_uint(acc[4 * b + r]) ^ osg[r];
-            lds_barrier<THREADS>();
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b < nitems) {
-                    const uint4v v = *(__attribute__((address_space(3))) const uint4v*)(lds + uint32_t(b) * ITEM_BYTES + uint32_t(tid) * 16u);
-                    reinterpret_cast<uint4v*>(p.out + (item0 + b) * p.out_stride)[tid] = v;
-                }
-            }
-        } else {
-            // ---- results -> graded rows: (uniform) row base + the lane's byte offsets ----
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b < nitems) {
-                    unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + (item0 + b) * p.out_stride);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (ook[r]) {
-                            float* q = reinterpret_cast<float*>(orow + ooff[r]);
-                            const float v = __uint_as_float(__float_as_uint(acc[4 * b + r]) ^ osg[r]);
-                            *q = p.beta ? *q + v : v;
-                        }
-                    }
-                }
-            }
-        }
-        lds_barrier<THREADS>();   // the LDS images are rewritten by the next group
     }
 }
 

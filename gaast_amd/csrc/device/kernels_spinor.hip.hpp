@@ -152,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
     constexpr int LAM = LAMBIT >= 0 ? (1 << LAMBIT) : 0;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    wave_slot_priority();
 
     // Vector instructions are what this kernel pays for (they take matrix-pipe time, LDS and global accesses do not), so
     // the 16-bit table entries are expanded ONCE per launch into the form the per-item code consumes with two

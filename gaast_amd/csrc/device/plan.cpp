@@ -22,12 +22,6 @@
 #include <map>
 #include <stdexcept>
 
-// f32 at n = 8, 9: 1 = k_gp_mfma16x4<float> (one item per workgroup; measured 8-10 % faster), 0 = k_gp_mfma16 (four items per
-// v_mfma_f32_16x16x1_4b_f32); a build-time switch for A/B runs (make KFLAGS=-DGAAST_F32_MFMA16X4=0 OUTDIR=...)
-#ifndef GAAST_F32_MFMA16X4
-#define GAAST_F32_MFMA16X4 1
-#endif
-
 namespace gaast {
 namespace {
 
@@ -407,7 +401,7 @@ struct Lowering {
         return true;
     }
 
-    // which dense kernel (0 = none, 1 = k_gp_dense, 2 = k_gp_mfma16, 3 = k_gp_mfma32, 4 = k_gp_mfma16d) and in which basis
+    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>) and in which basis
     int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
         const int n = d.vec_space_dim;
@@ -424,10 +418,7 @@ struct Lowering {
         // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (four items per wave)
         if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
         if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
-#if GAAST_F32_MFMA16X4
-        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 4;
-#endif
-        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 2;
+        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 4;   // k_gp_mfma16x4<float>
         // f64 (the reference's value type), n = 8, 9: v_mfma_f64_16x16x4_f64, one item per workgroup (at n = 10 the kernel
         // exists and is correct but measures the same as the vector form: 22.3 M products/s either way)
         if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 12 &&
@@ -576,7 +567,7 @@ struct Lowering {
             s.n_entries = nd.n_comp_muls;
             const int n = d.vec_space_dim;
             s.use_mfma = dense_kind == 3;
-            s.use_mfma16 = dense_kind == 2 || dense_kind == 4;
+            s.use_mfma16 = dense_kind == 4;
             s.use_mfma16d = dense_kind == 4;
             s.mfma16_quads = dense_kind == 4 && plan.dtype == GAAST_F32;   // k_gp_mfma16x4<float>: B words in 16-byte quads
             s.mfma32_pairs = dense_kind == 3 && n <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
@@ -604,12 +595,6 @@ struct Lowering {
             auto vec_pos = [](uint32_t m) {  // dense_lds_pos
                 const uint32_t x = m >> 4, lo = m & 15;
                 return (x << 4) | ((((lo >> 2) ^ (x >> 2)) & 3) << 2) | (lo & 3);
-            };
-            // k_gp_mfma16's B image: the words of block x stored even-|k| first (term order mfma16_k), quads rotated as above
-            auto mfma16_b_pos = [](uint32_t m) {
-                static const int word_of_k[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
-                const uint32_t x = m >> 4, w = uint32_t(word_of_k[m & 15]);
-                return (x << 4) | ((((w >> 2) ^ (x >> 2)) & 3) << 2) | (w & 3);
             };
             // k_gp_mfma32p's B image: the lane's 16 words (k of one parity) even-|k >> 1| first, quads rotated as in mfma_b_pos
             auto mfma32p_b_pos = [](uint32_t m) {
@@ -653,8 +638,7 @@ struct Lowering {
                         const uint32_t pos = s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
                                              : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
                                              : s.mfma16_quads ? (right ? mfma16q_b_pos(blade) : blade)
-                                             : s.use_mfma16d ? (right ? mfma16d_b_pos(blade) : blade)
-                                             : s.use_mfma16 ? (right ? mfma16_b_pos(blade) : blade) : vec_pos(blade);
+                                             : s.use_mfma16d ? (right ? mfma16d_b_pos(blade) : blade) : vec_pos(blade);
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();
                         map.push_back(off | (pos << 16) | sgn);

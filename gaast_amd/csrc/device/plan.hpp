@@ -38,6 +38,7 @@ struct Step {
     enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG } kind = ZERO;
     BufRef res, a, b;
     std::string name;
+    std::string hip_kernel;        // the HIP kernel (template and arguments) prepare_step picked: appended to the launch label
     // host images of the tables (uploaded once at program_create)
     std::vector<uint32_t> u32_a;   // AXPY map | FLIP offsets | CSR row_start | DENSE left_map
     std::vector<uint32_t> u32_b;   // CSR row_out | DENSE right_map
@@ -68,8 +69,8 @@ struct Step {
     int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)
     int degenerate = 0;
     int use_mfma = 0;
-    int use_mfma16 = 0;  // k_gp_mfma16 (f32, n = 8, 9) or k_gp_mfma16d
-    int use_mfma16d = 0; // k_gp_mfma16x4<T> (one item per workgroup): with use_mfma16
+    int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
+    int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)
     int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout
     int mfma32_pairs = 0;  // k_gp_mfma32p (image-pair form, f32, n = 10 ... 13) instead of k_gp_mfma32
     int spinor_lam_bit = -1, spinor_has_alpha = 0;  // index basis of the matrix-representation kernels: spinor_basis.hpp

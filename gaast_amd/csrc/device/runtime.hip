@@ -178,6 +178,8 @@ int resident_blocks(const void* kern, int threads, size_t lds, int* per_cu) {
 template <typename T>
 int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
     constexpr bool is_f64 = std::is_same<T, double>::value;
+    const std::string tn = is_f64 ? "double" : "float";
+    const std::string dg = s.degenerate ? "true" : "false";
     switch (s.kind) {
     case Step::PRODUCT_CSR: {
         const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
@@ -195,6 +197,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             using KernE = void (*)(EllArgs<T>);
             const KernE tab[2][4] = {{&k_product_ell<T, 1, false>, &k_product_ell<T, 2, false>, &k_product_ell<T, 4, false>, &k_product_ell<T, 8, false>},
                                      {&k_product_ell<T, 1, true>, &k_product_ell<T, 2, true>, &k_product_ell<T, 4, true>, &k_product_ell<T, 8, true>}};
+            s.hip_kernel = "k_product_ell<" + tn + ",1.." + std::to_string(items) + "," + (s.ell_bytes ? "true" : "false") + ">";
             for (int l2 = 0; (1 << l2) <= items; ++l2) {
                 s.kern[l2] = reinterpret_cast<const void*>(tab[s.ell_bytes ? 1 : 0][l2]);
                 if (int st = allow_lds(s.kern[l2], per_item << l2)) return st;
@@ -209,6 +212,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         if (items < 1) items = 1;
         s.max_items = items;
         s.kern[0] = reinterpret_cast<const void*>(&k_product_csr<T>);
+        s.hip_kernel = "k_product_csr<" + tn + ">";
         return allow_lds(s.kern[0], per_item * size_t(items));
     }
     case Step::PRODUCT_DENSE: {
@@ -231,6 +235,8 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             else if (m == 5) kern = lb5 == 4 ? &k_gp_spinor_wave1<5, 4> : lb5 == 3 ? &k_gp_spinor_wave1<5, 3> : &k_gp_spinor_wave1<5, -1>;
             else kern = lb5 == 3 ? &k_gp_spinor_wave1<4, 3> : lb5 == 2 ? &k_gp_spinor_wave1<4, 2> : &k_gp_spinor_wave1<4, -1>;
             s.kern[0] = reinterpret_cast<const void*>(kern);
+            s.hip_kernel = (m == 6 ? (is_f64 ? "k_gp_spinor12d<" : "k_gp_spinor12s<") : (is_f64 ? "k_gp_spinor_wave1d<" : "k_gp_spinor_wave1<") + std::to_string(m) + ",") +
+                           std::to_string(lb5) + ">";
             s.threads = m == 6 ? 256 : 64;
             if (int st = allow_lds(s.kern[0], s.lds)) return st;
             return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
@@ -249,6 +255,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                                         : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12> : &k_gp_mfma32p<false, 12>)
                                                   : (s.degenerate ? &k_gp_mfma32p<true, 13> : &k_gp_mfma32p<false, 13>);
                     s.kern[0] = reinterpret_cast<const void*>(kernp);
+                    s.hip_kernel = "k_gp_mfma32p<" + dg + "," + std::to_string(n) + ">";
                     if (int st = allow_lds(s.kern[0], s.lds)) return st;
                     return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
                 }
@@ -258,6 +265,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                             : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>)
                                                : (s.degenerate ? &k_gp_mfma32<true, 1024> : &k_gp_mfma32<false, 1024>);   // n = 14: 16 waves, 128 KiB of LDS
                 s.kern[0] = reinterpret_cast<const void*>(kern);
+                s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + ">";
                 return allow_lds(s.kern[0], s.lds);
             }
         }
@@ -285,28 +293,10 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
             s.kern[2] = reinterpret_cast<const void*>(kw);
+            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + ",0|1|2>";   // staging / store mode: by alignment at launch
             for (int v = 0; v < 3; ++v)
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
-        }
-        if (s.use_mfma16) {
-            if constexpr (!is_f64) {
-                s.threads = 64 << (n - 8);                     // one wave per 16 result columns of a group of four items
-                s.items_per_block = 4;
-                s.lds = size_t(4) * size_t(4 * (size_t(1) << n) + 16) * sizeof(float);   // +A, -A, +B, -B images of four items
-                // [0]: general staging; [1]: register prefetch, when both operands are full rows that turn out
-                // contiguous and 16-byte aligned at launch
-                using KernD = void (*)(DenseArgs<float>);
-                const KernD general = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8, false> : &k_gp_mfma16<false, 8, false>)
-                                             : (s.degenerate ? &k_gp_mfma16<true, 9, false> : &k_gp_mfma16<false, 9, false>);
-                const KernD fast = n == 8 ? (s.degenerate ? &k_gp_mfma16<true, 8, true> : &k_gp_mfma16<false, 8, true>)
-                                          : (s.degenerate ? &k_gp_mfma16<true, 9, true> : &k_gp_mfma16<false, 9, true>);
-                s.kern[0] = reinterpret_cast<const void*>(general);
-                s.kern[1] = reinterpret_cast<const void*>(fast);
-                if (int st = allow_lds(s.kern[0], s.lds)) return st;
-                if (int st = allow_lds(s.kern[1], s.lds)) return st;
-                return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
-            }
         }
         const int lpi = 1 << (n - 4);
         s.threads = lpi > 256 ? lpi : 256;
@@ -323,6 +313,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             kern = s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false> : &k_gp_dense<T, false, 256, false>)
                                     : (s.degenerate ? &k_gp_dense<T, true, 512, false> : &k_gp_dense<T, false, 512, false>);
         s.kern[0] = reinterpret_cast<const void*>(kern);
+        s.hip_kernel = "k_gp_dense<" + tn + "," + dg + "," + std::to_string(s.threads) + "," + (s.neg_lo_all ? "true" : "false") + ">";
         if (int st = allow_lds(s.kern[0], s.lds)) return st;
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
@@ -490,7 +481,6 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.zero_hi = s.zero_hi;
         p.neg_lo = s.neg_lo;
         p.beta = s.beta;
-        p.out_rows = s.use_mfma16 && s.out_full && !s.beta && aligned(res.ptr, res.stride);
         p.batch = batch;
         using KernD = void (*)(DenseArgs<T>);
         const int64_t groups = (batch + s.items_per_block - 1) / s.items_per_block;
@@ -750,7 +740,8 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         s.coeff_host = s.kind == Step::FUSED ? s.coeff : std::vector<double>();
         std::vector<uint32_t>().swap(s.u32_c);
         std::vector<double>().swap(s.coeff);
-        prog->launch_names.push_back(s.name);
+        // launch label: what the step is, then WHICH HIP kernel runs it (the name rocprofv3 reports)
+        prog->launch_names.push_back(s.hip_kernel.empty() ? s.name : s.name + " :: " + s.hip_kernel);
     }
     prog->const_mvs.assign(plan.inputs.size(), nullptr);
     for (size_t i = 0; i < plan.inputs.size(); ++i) {

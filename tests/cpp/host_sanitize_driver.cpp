@@ -84,12 +84,6 @@ static uint32_t mfma_b_pos(uint32_t m) {
     return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
 }
 
-// k_gp_mfma16's B image: the words of block x stored even-|k| first, quads rotated (plan.cpp: mfma16_b_pos)
-static uint32_t mfma16_b_pos(uint32_t m) {
-    static const int word_of_k[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
-    const uint32_t x = m >> 4, w = uint32_t(word_of_k[m & 15]);
-    return (x << 4) | ((((w >> 2) ^ (x >> 2)) & 3) << 2) | (w & 3);
-}
 // k_gp_mfma32p's B image (plan.cpp: mfma32p_b_pos)
 static uint32_t mfma32p_b_pos(uint32_t m) {
     static const int word_of_s[16] = {0, 8, 9, 1, 10, 2, 3, 11, 12, 4, 5, 13, 6, 14, 15, 7};
@@ -148,7 +142,6 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
     else if (st->mfma16_quads) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16q_b_pos(m)] = m;
     else if (st->use_mfma16d) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16d_b_pos(m)] = m;
-    else if (st->use_mfma16) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16_b_pos(m)] = m;
     auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
         std::vector<double> img(N, 0.0);
         for (uint32_t w : map) {

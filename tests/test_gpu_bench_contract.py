@@ -74,6 +74,24 @@ def test_a_failed_gather_ends_the_job_non_zero(tmp_path):
     assert d["value"] > 0 and "error" in d["gather"]
 
 
+def test_default_line_carries_the_other_single_gpu_configs():
+    """The DEFAULT run (no --workload, no --batch) also times BASELINE configs[1] (R^8 f32), configs[4] (R^{4,1} sandwich,
+    f64) and R^12 in f64, each with its own roofline object, so that they stop resting on builder-run profiles."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-alt", "--no-latency"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([l for l in run.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["batch_per_gpu"] == 65536 and d["roofline"]["kernel"].endswith(":: k_gp_mfma32p<false,12>")
+    side = {c["key"]: c for c in d["configs"]}
+    assert set(side) == {"r8", "cl41", "r12d"}
+    for key, bound, kern in (("r8", "mfma", "k_gp_mfma16x4<float,false,8,"), ("cl41", "hbm", "ast_jit"), ("r12d", "mfma", "k_gp_mfma16x4<double,false,12,")):
+        c = side[key]
+        assert "error" not in c, c
+        r = c["roofline"]
+        assert r["bound"] == bound and kern in r["kernel"] and 0.3 < r["frac"] < 1.0 and c["value"] > 0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
 def test_bench_default_multi_gpu_workload_is_config_4(monkeypatch):
     """Without --batch, N > 1 runs BASELINE configs[3]: 1,048,576 input sets cut into contiguous shards."""
     from gaast_amd.sharding import shard_range

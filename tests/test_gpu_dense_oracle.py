@@ -24,7 +24,9 @@ def _gp(n, left_grades=None):
 
 
 def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
-    """variants: [(dtype, flags, expected launch-name prefix)]; one oracle evaluation serves them all"""
+    """variants: [(dtype, flags, expected launch-name prefix, HIP kernel)]; one oracle evaluation serves them all.  The launch
+    label names the HIP kernel instantiation prepare_step picked ("<what> :: <kernel<...>>", the name rocprofv3 reports):
+    the test asserts it, so a docstring cannot go stale about which kernel it covers."""
     build, lg = _gp(n, left_grades)
     rng = np.random.default_rng(seed)
     rows = {0: rows_of(n, lg, batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
@@ -32,10 +34,10 @@ def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
     alg = metric if any(m != 1.0 for m in metric) else n
     want, wmask = oracle_eval_batch(build, alg, rows64, batch)
     og = [k for k in range(n + 1) if (wmask >> k) & 1]
-    for dtype, flags, prefix in variants:
+    for dtype, flags, prefix, kernel in variants:
         got, mask, spec = hip_eval_batch(build, alg, rows if dtype == ga.F32 else rows64, batch, dtype=dtype, flags=flags)
         assert mask == wmask
-        assert any(l.startswith(prefix) for l in spec.launches()), (prefix, spec.launches())
+        assert any(l.startswith(prefix) and l.split(" :: ")[-1].startswith(kernel) for l in spec.launches()), (prefix, kernel, spec.launches())
         eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
         for i in range(batch):
             S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, full_grades(n), rows64[1][i]))
@@ -46,36 +48,45 @@ def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
 
 
 def test_n10_f64_matrix_core_and_vector_kernels():
-    """k_gp_mfma16d<false, 10> (four waves per item) and, behind GAAST_FLAG_NO_MFMA, k_gp_dense<double, false, 256>: 64 lanes
-    per item, four items per workgroup"""
-    _check(10, [1.0] * 10, None, [(ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=5, seed=10)
+    """k_gp_mfma16x4<double, false, 10> (four waves per item) and, behind GAAST_FLAG_NO_MFMA, k_gp_dense<double, false, 256>:
+    64 lanes per item, four items per workgroup"""
+    _check(10, [1.0] * 10, None, [(ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,10,"),
+                                  (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,false,256,false>")], batch=5, seed=10)
 
 
 def test_n11_f32_two_waves_per_item_and_f64():
-    """k_gp_mfma32<false, 256> with 2 waves per item (2 items per workgroup, ragged last workgroup); k_gp_dense f32 / f64"""
-    _check(11, [1.0] * 11, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
-                                  (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=3, seed=11)
+    """k_gp_mfma32p<false, 11> with 2 waves per item (2 items per workgroup, ragged last workgroup); k_gp_mfma16x4<double>
+    with 8 waves per item; k_gp_dense f32 / f64"""
+    _check(11, [1.0] * 11, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,11>"),
+                                  (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<float,false,256,false>"),
+                                  (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,11,"),
+                                  (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,false,256,false>")], batch=3, seed=11)
 
 
 def test_n12_f32_and_f64_against_the_oracle():
-    """BASELINE configs[2] kernel (k_gp_mfma32<false, 256>, 4 waves per item) and the f64 workload r12d
-    (k_gp_dense<double, false, 256>), two items, all 4096 components, against the reference's 16.7 M-entry table"""
-    _check(12, [1.0] * 12, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
-                                  (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=2, seed=12)
+    """BASELINE configs[2] kernel (k_gp_mfma32p<false, 12>, 4 waves per item) and the f64 workload r12d
+    (k_gp_mfma16x4<double, false, 12>, 16 waves per item), the vector kernels behind GAAST_FLAG_NO_MFMA: two items, all 4096
+    components, against the reference's 16.7 M-entry table"""
+    _check(12, [1.0] * 12, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,12>"),
+                                  (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<float,false,256,false>"),
+                                  (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,12,"),
+                                  (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,false,256,false>")], batch=2, seed=12)
 
 
 def test_n12_mixed_signature_negative_vectors_among_lo_and_hi_bits():
     """-1 at positions 1, 3 (lo bits of every kernel), 7, 10 (hi bits): the matrix-core kernel takes the lo signs as lane
     constants; the vector kernel needs four like-signed lo vectors and gets them by a basis permutation"""
     metric = [1.0, -1.0, 1.0, -1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0]
-    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=1, seed=13)
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,12>"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,12,"),
+                              (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,false,256,")], batch=1, seed=13)
 
 
 def test_n12_degenerate_metric_null_vector_first():
     """the reference's PGA habit of putting the null vector first (eval.rs:132), at n = 12, plus a -1 and a second null
     vector: the basis permutation moves the null vectors to the hi bits"""
     metric = [0.0, 1.0, 1.0, 1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0]
-    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma["), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[")], batch=1, seed=14)
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<true,12>"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,true,12,"),
+                              (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,true,256,")], batch=1, seed=14)
 
 
 @pytest.mark.parametrize("n", [8, 10, 11])
@@ -83,25 +94,30 @@ def test_partial_left_operand_takes_the_general_staging(n):
     """a left operand that holds only some grades (zeros elsewhere, no 16-byte-piece fast path): k_gp_mfma16x4<float>
     (n = 8), k_gp_mfma32p (n = 10, 11) and k_gp_mfma16x4<double> (1, 4, 8 waves per item) through their general staging"""
     lg = [0, 1, 2, 3, 4, 5, 6] if n == 8 else [0, 1, 2, 3, 4, 5, 6, 7]   # enough entries for the dense kernels (>= 4^n / 8)
-    _check(n, [1.0] * n, lg, [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma[")], batch=3, seed=40 + n)
+    f32_kernel = "k_gp_mfma16x4<float,false,8," if n == 8 else f"k_gp_mfma32p<false,{n}>"
+    _check(n, [1.0] * n, lg, [(ga.F32, 0, "product_dense_mfma[", f32_kernel), (ga.F64, 0, "product_dense_mfma[", f"k_gp_mfma16x4<double,false,{n},")], batch=3, seed=40 + n)
 
 
 def test_n13_eight_waves_per_item_512_thread_kernels():
-    """k_gp_mfma32<false, 512> (8 waves per item), k_gp_dense<float, false, 512>, k_gp_dense<double, false, 512>"""
-    _check(13, [1.0] * 13, [0, 1, 2, 3, 4, 5], [(ga.F32, 0, "product_dense_mfma["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense["),
-                                                (ga.F64, 0, "product_dense[")], batch=1, seed=15)
+    """k_gp_mfma32p<false, 13> (512 threads, 8 waves per item), k_gp_dense<float, false, 512>, k_gp_dense<double, false, 512>"""
+    _check(13, [1.0] * 13, [0, 1, 2, 3, 4, 5], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,13>"),
+                                                (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<float,false,512,false>"),
+                                                (ga.F64, 0, "product_dense[", "k_gp_dense<double,false,512,false>")], batch=1, seed=15)
 
 
 @pytest.mark.parametrize("metric", [[0.0] + [1.0] * 7, [-1.0] + [1.0] * 7, [-1.0] * 8, [1.0, 0.0, -1.0, 1.0, 0.0, -1.0, 1.0, -1.0],
                                     [-1.0, -1.0, 1.0, 0.0, -1.0, -1.0, 1.0, 1.0, -1.0]])
 def test_n8_n9_any_diagonal_metric_stays_on_the_dense_kernels(metric):
-    """PGA-style null vector first, STA-style time first, Cl(0,8), and mixtures: k_gp_mfma16 in f32 and k_gp_mfma16d in
-    f64 (lane-constant lo signs), k_gp_dense in both types behind GAAST_FLAG_NO_MFMA (permutation to four like-signed lo
+    """PGA-style null vector first, STA-style time first, Cl(0,8), and mixtures: k_gp_mfma16x4<float> and k_gp_mfma16x4<double>
+    (lane-constant lo signs), k_gp_dense in both types behind GAAST_FLAG_NO_MFMA (permutation to four like-signed lo
     vectors; NEGLO instantiation for Cl(0,8))"""
     n = len(metric)
-    variants = [(ga.F32, 0, "product_dense_mfma["), (ga.F64, 0, "product_dense_mfma[")]
+    dg = "true" if 0.0 in metric else "false"
+    variants = [(ga.F32, 0, "product_dense_mfma[", f"k_gp_mfma16x4<float,{dg},{n},"), (ga.F64, 0, "product_dense_mfma[", f"k_gp_mfma16x4<double,{dg},{n},")]
     if sum(m == 1.0 for m in metric) >= 4 or sum(m == -1.0 for m in metric) >= 4:
-        variants += [(ga.F64, ga.FLAG_NO_MFMA, "product_dense["), (ga.F32, ga.FLAG_NO_MFMA, "product_dense[")]
+        neglo = "true" if sum(m == 1.0 for m in metric) < 4 else "false"
+        variants += [(ga.F64, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<double,{dg},256,{neglo}>"),
+                     (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<float,{dg},256,{neglo}>")]
     _check(n, metric, None, variants, batch=9, seed=80 + n)
 
 
@@ -179,7 +195,7 @@ def test_n14_sixteen_waves_per_item_against_a_sparse_left_operand():
     B = rng.uniform(-1, 1, (batch, N)).astype(np.float32)
     build, _ = _gp(n)
     got, mask, spec = hip_eval_batch(build, metric, {0: A, 1: B}, batch, dtype=ga.F32)
-    assert any(l.startswith("product_dense_mfma[gp n=14") for l in spec.launches()), spec.launches()
+    assert any(l.startswith("product_dense_mfma[gp n=14") and l.endswith(":: k_gp_mfma32<false,1024>") for l in spec.launches()), spec.launches()
     neg = sum(1 << i for i, g in enumerate(metric) if g < 0)
     bmask = np.arange(N, dtype=np.int64)
     for i in range(batch):
@@ -210,3 +226,27 @@ def test_n14_sixteen_waves_per_item_against_a_sparse_left_operand():
         want = np.zeros(N, np.float32)
         want[pos_of[res]] = coeff
         assert np.array_equal(got[i], want), i
+
+
+@pytest.mark.parametrize("n,dtype", [(8, ga.F32), (8, ga.F64), (10, ga.F64), (10, ga.F32)])
+def test_negative_zero_operands_leave_no_trace(n, dtype):
+    """The FAST staging of k_gp_mfma16x4 does not apply the `0.0 + x` of the reference's operand copy (graded.rs:74): a -0.0
+    component can only contribute +-0 to sums that start from +0.0, so the results -- all-zero sums included -- must equal, BIT
+    FOR BIT, those of the same rows with every -0.0 replaced by +0.0, and no result may be -0.0 where the reference has +0.0.
+    Rows: random values with a third of the components set to -0.0, plus rows that are entirely +-0.0."""
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(99 + n)
+    batch = 6
+    build, lg = _gp(n)
+    rows = {s: rows_of(n, lg, batch, rng, npdt) for s in range(2)}
+    for s in range(2):
+        holes = rng.random(rows[s].shape) < 0.33
+        rows[s][holes] = -0.0
+    rows[0][4, :] = -0.0                      # (-0) * B: every sum is a sum of zeros
+    rows[1][5, :] = -0.0
+    clean = {s: np.where(rows[s] == 0, npdt(0.0), rows[s]) for s in range(2)}
+    got, _, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+    ref, _, _ = hip_eval_batch(build, n, clean, batch, dtype=dtype)
+    assert any("product_dense_mfma[" in l for l in spec.launches())
+    assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
+    assert not np.signbit(got[4]).any() and not np.signbit(got[5]).any() and not got[4].any()
