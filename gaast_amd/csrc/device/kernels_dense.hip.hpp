@@ -50,6 +50,12 @@ struct DenseArgs {
     uint32_t neg_hi, zero_hi;   // metric signature of basis vectors 4.. (bit i <-> vector 4+i)
     uint32_t neg_lo;            // lo basis vectors that square to -1
     int beta;
+    // general diagonal metric (entries other than +-1 / 0): the kernels work in the rescaled basis f_i = e_i / sqrt|g_i|, whose
+    // metric is +-1 / 0.  Per loaded component: w_S = prod_{i in S} sqrt|g_i| (operands); per permuted blade: 1 / w_T
+    // (result).  NULL for +-1 / 0 metrics.
+    const T* left_scale;
+    const T* right_scale;
+    const T* out_scale;
     int left_signs;             // some left_map word has its negate bit set (folded sign arms, permuted basis)
     int out_signs;              // some out_map word has its sign bit set (permuted basis)
     int64_t batch;
@@ -72,7 +78,7 @@ __device__ __forceinline__ int dense_lds_pos(int m) {
 template <typename T, int THREADS>
 __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_t stride, const uint32_t* __restrict__ map,
                                                int count, int contig4, int canon, T* __restrict__ images,
-                                               int image_stride, int nitems, int tid) {
+                                               int image_stride, int nitems, int tid, const T* __restrict__ scale = nullptr) {
     constexpr int U = 4;
     if (contig4) {
         const int total4 = (nitems * count) >> 2;  // count % 4 == 0
@@ -107,6 +113,7 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
                     for (int c = 0; c < 4; ++c) {
                         T x = v[k][c];
                         if (canon) x = T(0) + x;  // the reference's zero-init + add_grades_from copy: 0.0 + x
+                        if (scale) x = x * scale[((e - (e / count4) * count4) << 2) + c];   // rescaled basis: w_S A_S
                         if (mm[c] >> 31) x = -x;  // a folded Negation / Reverse / GradeInvolution of this grade
                         img[(mm[c] >> 16) & 0x7fffu] = x;
                     }
@@ -135,6 +142,7 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
             if (e < total) {
                 T x = v[k];
                 if (canon) x = T(0) + x;
+                if (scale) x = x * scale[e % count];
                 if (m[k] >> 31) x = -x;
                 images[(e / count) * image_stride + ((m[k] >> 16) & 0x7fffu)] = x;
             }
@@ -145,10 +153,12 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
 // result component -> graded row: out_map word = offset | negate << 30 (the blade's reordering sign under the basis
 // permutation), -1 = not produced
 template <typename T>
-__device__ __forceinline__ void store_result(T* __restrict__ orow, int32_t w, T v, int beta) {
+__device__ __forceinline__ void store_result(T* __restrict__ orow, int32_t w, T v, int beta, const T* __restrict__ out_scale = nullptr,
+                                             int blade = 0) {
     if (w < 0) return;
     const int32_t off = w & 0x3fffffff;
-    if (w & 0x40000000) v = -v;
+    if (out_scale) v = v * out_scale[blade];   // back from the rescaled basis: C_T = C'_T / w_T
+    if (w & 0x40000000) v = beta ? -v : T(0) + (-v);   // reordering sign; a zero result stays +0.0 as in the reference
     orow[off] = beta ? orow[off] + v : v;
 }
 
@@ -312,9 +322,9 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
                 __syncthreads();
             }
             stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid);
+                                       p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
             stage_operands<T, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, p.right_scale);
         }
         __syncthreads();
 
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
             // ---- scatter the 16 accumulators to their positions in the graded row ----
             T* orow = p.out + (item0 + it) * p.out_stride;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) store_result<T>(orow, om[i], acc.get(i), p.beta);
+            for (int i = 0; i < 16; ++i) store_result<T>(orow, om[i], acc.get(i), p.beta, p.out_scale, (c_hi << 4) + i);
         }
         __syncthreads();  // the LDS image is rewritten by the next group
     }
@@ -416,9 +426,9 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
     {
         stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid);
+                                       p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
         stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid);
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, p.right_scale);
     }
     __syncthreads();
 
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-            store_result<float>(orow, om[c_lo], acc[r], p.beta);
+            store_result<float>(orow, om[c_lo], acc[r], p.beta, p.out_scale, (c_hi << 5) + c_lo);
         }
     }
 }
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
     static_assert(MPR * ROWS == 8, "eight 16-byte pieces per thread and group");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
-    const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full;
+    const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full && !p.left_scale;   // (a rescaled basis: general staging)
 
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
 
@@ -694,9 +704,9 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                 lds_barrier<THREADS>();
             }
             stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                           p.canon_left, smem, item_stride, nitems, tid);
+                                           p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
             stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid);
+                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid, p.right_scale);
             lds_barrier<THREADS>();
             constexpr int quads_per_item = N >> 1;        // 16-byte pieces of +A and +B together
             for (int e = tid; e < nitems * quads_per_item; e += THREADS) {
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-                store_result<float>(orow, om[c_lo], acc[r], p.beta);
+                store_result<float>(orow, om[c_lo], acc[r], p.beta, p.out_scale, (c_hi << 5) + c_lo);
             }
         }
         lds_barrier<THREADS>();   // the images are rewritten by the next group
@@ -1000,12 +1010,15 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
     // where this lane's results go: register r = row c_lo = MM::row(kq, r) of column c_hi
     uint32_t ooff[4], osg[4];
     bool ook[4];
+    T osc[4];   // general diagonal metric: 1 / w_T of the lane's four result blades (MODE <= 1 only: the host keeps such
+                // products on the general staging and the general stores)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int32_t w = p.out_map[(c_hi << 4) + MM::row(kq, r)];
         ook[r] = w >= 0;
         ooff[r] = uint32_t(w & 0x3fffffff) << ES;
         osg[r] = (uint32_t(w) & 0x40000000u) << 1;
+        osc[r] = (MODE <= 1 && p.out_scale) ? p.out_scale[(c_hi << 4) + MM::row(kq, r)] : T(1);
     }
 
     // FAST: byte address inside the +A / +B image and negate bit of the thread's four components per row
@@ -1061,9 +1074,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                 lds_barrier<THREADS>();
             }
             stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem + A_EL, item_stride, 1, tid);
+                                       p.canon_left, smem + A_EL, item_stride, 1, tid, p.left_scale);
             stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid);
+                                       p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid, p.right_scale);
             lds_barrier<THREADS>();
             for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images: -B N further, -A N + PAD_A further
                 if (e < N) smem[B_EL + N + e] = -smem[B_EL + e];
@@ -1178,7 +1191,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
             for (int r = 0; r < 4; ++r) {
                 if (ook[r]) {
                     T* q = reinterpret_cast<T*>(orow + ooff[r]);
-                    T v = MM::flip(acc[r], osg[r]);
+                    T v = acc[r];
+                    if (p.out_scale) v = v * osc[r];       // back from the rescaled basis
+                    v = MM::flip(v, osg[r]);
                     if (osg[r] && !p.beta) v = T(0) + v;   // a zero result stays +0.0 under a negated reordering sign
                     *q = p.beta ? *q + v : v;
                 }

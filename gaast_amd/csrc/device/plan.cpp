@@ -16,6 +16,7 @@
 #include "spinor_basis.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -377,10 +378,10 @@ struct Lowering {
     // kernel: compile-time sign pattern).  The identity is kept whenever it already qualifies.
     bool dense_basis_permutation(int L, bool uniform, std::vector<int>& perm) const {
         const int n = d.vec_space_dim;
-        std::vector<int> plus, minus;
+        std::vector<int> plus, minus;   // by the SIGN of the square: a general entry g is rescaled to g / |g| (dense_scales)
         for (int i = 0; i < n; ++i) {
-            if (d.metric_diag[i] == 1.0) plus.push_back(i);
-            if (d.metric_diag[i] == -1.0) minus.push_back(i);
+            if (d.metric_diag[i] > 0.0) plus.push_back(i);
+            if (d.metric_diag[i] < 0.0) minus.push_back(i);
         }
         std::vector<int> lo;
         if (uniform) {
@@ -401,16 +402,51 @@ struct Lowering {
         return true;
     }
 
+    // General diagonal metric on the dense kernels.  e_i = r_i f_i with r_i = sqrt|g_i| (1 for a null vector) gives a basis
+    // whose metric is sign(g_i) in {+1, -1, 0}; a blade e_S = w_S f_S, w_S = prod_{i in S} r_i.  So
+    //     C_T = (1 / w_T) * sum_{S ^ U = T} s'(S, U) (w_S A_S) (w_U B_U),
+    // s' the sign-metric coefficient: w_S w_U / w_T = prod_{i in S & U} |g_i| is the reference's coefficient magnitude
+    // (algebra.rs:78-81).  The operands are multiplied by w while they are staged, the result by 1 / w_T when it is stored:
+    // three more roundings per term than the +-1 / 0 case (the factors themselves are rounded once, from long double).
+    // Used only when every w_S and 1 / w_S stays within 2^+-40 (f32) / 2^+-300 (f64) -- no overflow or gradual underflow
+    // introduced by the rescaling for operands of ordinary magnitude; otherwise the exact list kernels keep the product.
+    bool metric_is_unit() const {
+        for (int i = 0; i < d.vec_space_dim; ++i) {
+            const double g = d.metric_diag[i];
+            if (g != 1.0 && g != -1.0 && g != 0.0) return false;
+        }
+        return true;
+    }
+    bool dense_scales_ok() const {
+        if (metric_is_unit()) return true;
+        long double up = 1.0L, down = 1.0L;
+        for (int i = 0; i < d.vec_space_dim; ++i) {
+            const double g = d.metric_diag[i];
+            if (!(g == g) || g == 1.0 / 0.0 || g == -1.0 / 0.0) return false;
+            if (g == 0.0) continue;
+            const long double r = sqrtl(fabsl((long double)g));
+            if (r > 1.0L) up *= r;
+            else down *= r;
+        }
+        const long double lim = plan.dtype == GAAST_F32 ? 0x1p40L : 0x1p300L;
+        return up <= lim && down >= 1.0L / lim;
+    }
+    long double blade_scale(uint32_t S) const {   // w_S
+        long double w = 1.0L;
+        for (int i = 0; i < d.vec_space_dim; ++i)
+            if (((S >> i) & 1u) && d.metric_diag[i] != 0.0) w *= sqrtl(fabsl((long double)d.metric_diag[i]));
+        return w;
+    }
+
     // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>) and in which basis
     int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
         const int n = d.vec_space_dim;
         if (n < 6 || n > 14) return 0;  // small algebras: the exact kernel is HBM-bound anyway
         if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return 0;
-        for (int i = 0; i < n; ++i) {
-            const double g = d.metric_diag[i];
-            if (g != 1.0 && g != -1.0 && g != 0.0) return 0;
-        }
+        // A general diagonal metric (algebra.rs:148-165 multiplies by ANY base_vec_dot, :79-81) runs in the rescaled basis
+        // f_i = e_i / sqrt|g_i| (dense_scales); it needs finite, well-scaled factors, else the list kernels keep the product
+        if (!dense_scales_ok()) return 0;
         const double full = double(uint64_t(1) << (2 * n));
         if (double(nd.n_comp_muls) * 8.0 < full) return 0;  // the tiled kernels always do 4^n multiply-adds
         if (!is_geometric_list(nd)) return 0;
@@ -642,11 +678,13 @@ struct Lowering {
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();
                         map.push_back(off | (pos << 16) | sgn);
+                        if (s.scaled) (right ? s.coeff_b : s.coeff).push_back(double(blade_scale(orig)));
                     }
                 }
                 *full = map.size() == (size_t(1) << n);
                 *contig = seq && map.size() % 4 == 0 && !map.empty();
             };
+            s.scaled = metric_is_unit() ? 0 : 1;
             build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full, &s.left_contig);
             build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full, &s.right_contig);
             // out_map: indexed by the blade of the permuted basis; offset | reordering sign << 30, or -1
@@ -659,22 +697,26 @@ struct Lowering {
             // every blade produced into a row that holds nothing else: whole rows can be written in 16-byte pieces
             s.out_full = lr.row_len == (int64_t(1) << n);
             for (uint32_t m = 0; m < (1u << n); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
+            if (s.scaled) {
+                s.coeff_c.assign(size_t(1) << n, 0.0);
+                for (uint32_t m = 0; m < (1u << n); ++m) s.coeff_c[new_blade[m]] = double(1.0L / blade_scale(m));
+            }
             for (uint32_t w : s.u32_a) s.left_signs |= int(w >> 31);
             for (int32_t w : s.i32_a) s.out_signs |= int(w >= 0 && (uint32_t(w) & 0x40000000u));
             const int lo_bits = s.use_mfma ? 5 : 4;
             for (int j = 0; j < n; ++j) {
-                const double g = d.metric_diag[perm[size_t(j)]];
+                const double g = d.metric_diag[perm[size_t(j)]];   // only its sign matters here: the magnitude is in the scales
                 if (j < lo_bits) {
-                    if (g == -1.0) s.neg_lo |= 1u << j;
+                    if (g < 0.0) s.neg_lo |= 1u << j;
                 } else {
-                    if (g == -1.0) s.neg_hi |= 1u << (j - lo_bits);
+                    if (g < 0.0) s.neg_hi |= 1u << (j - lo_bits);
                     if (g == 0.0) s.zero_hi |= 1u << (j - lo_bits);
                 }
             }
             s.neg_lo_all = dense_kind == 1 && s.neg_lo == 15u;
             s.degenerate = s.zero_hi != 0;
             s.name = std::string(dense_kind == 1 ? "product_dense" : "product_dense_mfma") + "[gp n=" + std::to_string(n) +
-                     (identity ? "" : " permuted basis") + "]";
+                     (identity ? "" : " permuted basis") + (s.scaled ? " rescaled basis" : "") + "]";
             touch(res);
             return;
         }

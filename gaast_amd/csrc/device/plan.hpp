@@ -56,6 +56,12 @@ struct Step {
     int explog_res_k = -1, explog_res_0 = -1;// offsets in the result row, -1 = not produced
     std::vector<double> coeff_b;
     void* d_coeff_b = nullptr;
+    // DENSE with a general diagonal metric (entries other than +-1 / 0): the kernels run in the rescaled basis
+    // f_i = e_i / sqrt|g_i|: coeff = w_S per loaded left component, coeff_b = per loaded right component, coeff_c = 1 / w_T per
+    // blade of the permuted basis (the index of i32_a)
+    std::vector<double> coeff_c;
+    void* d_coeff_c = nullptr;
+    int scaled = 0;
     void* d_domain = nullptr;                // the program's domain-error counter (device, not owned by the step)
     int ell_bytes = 0;             // ... and the offsets of its entries are byte offsets
     int ell_width = 0;             // PRODUCT_CSR with rows of one length and +-1 coefficients: u32_c is [term][row], sign in bit 31

@@ -98,7 +98,7 @@ namespace {
 // device tables and hiprtc modules of a plan (also called before a plan is rebuilt)
 void release_plan_resources(Plan& plan) {
     for (Step& s : plan.steps) {
-        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b}) {
+        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b, &s.d_coeff_c}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -491,7 +491,10 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         }
         p.left_signs = s.left_signs;
         p.out_signs = s.out_signs;
-        const bool prefetch = s.use_mfma16 && s.kern[1] && p.left_contig && p.right_contig && p.left_full && p.right_full;
+        p.left_scale = s.scaled ? static_cast<const T*>(s.d_coeff) : nullptr;
+        p.right_scale = s.scaled ? static_cast<const T*>(s.d_coeff_b) : nullptr;
+        p.out_scale = s.scaled ? static_cast<const T*>(s.d_coeff_c) : nullptr;
+        const bool prefetch = s.use_mfma16 && s.kern[1] && p.left_contig && p.right_contig && p.left_full && p.right_full && !s.scaled;
         const bool whole_rows = prefetch && s.kern[2] && s.out_full && !s.beta;   // k_gp_mfma16x4: straight-line result stores
         hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[whole_rows ? 2 : prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);
@@ -734,6 +737,14 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
                 if (int st = upload_vec(cf, &s.d_coeff_b)) return st;
             } else {
                 if (int st = upload_vec(s.coeff_b, &s.d_coeff_b)) return st;
+            }
+        }
+        if (!s.coeff_c.empty()) {
+            if (plan.dtype == GAAST_F32) {
+                std::vector<float> cf(s.coeff_c.begin(), s.coeff_c.end());
+                if (int st = upload_vec(cf, &s.d_coeff_c)) return st;
+            } else {
+                if (int st = upload_vec(s.coeff_c, &s.d_coeff_c)) return st;
             }
         }
         // the host images of the big tables are no longer needed

@@ -142,8 +142,14 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
     else if (st->mfma16_quads) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16q_b_pos(m)] = m;
     else if (st->use_mfma16d) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16d_b_pos(m)] = m;
+    // a general diagonal metric: the step carries w_S per loaded component (coeff / coeff_b) and 1 / w_T per permuted blade
+    // (coeff_c); the test metrics have squares of powers of two, so every product below stays exact
+    CHECK(st->scaled == (st->coeff_c.empty() ? 0 : 1));
     auto image = [&](const std::vector<uint32_t>& map, const std::vector<double>& row, bool right) {
         std::vector<double> img(N, 0.0);
+        const std::vector<double>& scale = right ? st->coeff_b : st->coeff;
+        CHECK(!st->scaled || scale.size() == map.size());
+        size_t idx = 0;
         for (uint32_t w : map) {
             const uint32_t off = w & 0xffffu, pos = (w >> 16) & 0x7fffu;
             const uint32_t blade = (st->use_mfma || st->use_mfma16) ? (right ? inv_b[pos] : pos) : inv_vec[pos];
@@ -152,7 +158,8 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
             // c_hi part): taken out again here, the plain formula below applies
             if (right && (st->use_mfma16 || st->mfma32_pairs))
                 neg ^= uint32_t(__builtin_popcount(blade >> L) & __builtin_popcount(blade & ((1u << L) - 1u)) & 1);
-            img[blade] = neg ? -row[off] : row[off];
+            img[blade] = (neg ? -row[off] : row[off]) * (st->scaled ? scale[idx] : 1.0);
+            ++idx;
         }
         return img;
     };
@@ -174,7 +181,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     for (uint32_t m = 0; m < N; ++m) {
         const int32_t w = st->i32_a[m];
         if (w < 0) continue;
-        got[size_t(w & 0x3fffffff)] = (w & 0x40000000) ? -Cp[m] : Cp[m];
+        got[size_t(w & 0x3fffffff)] = ((w & 0x40000000) ? -Cp[m] : Cp[m]) * (st->scaled ? st->coeff_c[m] : 1.0);
     }
     // the reference's list (specialize.rs:162-183), on graded rows
     std::vector<double> want(N, 0.0);
@@ -299,6 +306,19 @@ int main() {
         dense_tables_agree_with_the_list(10, mix10, GAAST_F32, 0, "mfma32 tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
         dense_tables_agree_with_the_list(10, euclid, GAAST_F32, 0, "mfma32 tables n=10 euclid", "product_dense_mfma[gp n=10]");
         dense_tables_agree_with_the_list(10, mix10, GAAST_F64, 0, "mfma16d tables n=10 mixed", "product_dense_mfma[gp n=10 permuted basis]");
+        // general diagonal metrics (algebra.rs:148-165: any base_vec_dot): the rescaled basis.  Squares of powers of two keep
+        // every factor, product and sum exact, so the tables must reproduce the reference's list to the last bit.
+        const double gen8[8] = {4, 0.25, -16, 1, 1, -0.0625, 1, 64};
+        const double gen8z[8] = {0, 4, -0.25, 1, 16, 0, -1, 0.0625};
+        const double gen10[10] = {0.25, -4, 1, 16, -1, 1, 0, 0.0625, -16, 4};
+        const double gen7[7] = {4, 4, 0.25, 1, 16, -0.25, 1};
+        dense_tables_agree_with_the_list(8, gen8, GAAST_F32, 0, "mfma16x4 f32 tables n=8 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(8, gen8, GAAST_F64, 0, "mfma16x4 f64 tables n=8 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(8, gen8z, GAAST_F64, 0, "mfma16x4 f64 tables n=8 general metric with null vectors", "rescaled basis");
+        dense_tables_agree_with_the_list(8, gen8, GAAST_F64, GAAST_FLAG_NO_MFMA, "vector tables n=8 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(7, gen7, GAAST_F32, 0, "vector tables n=7 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(10, gen10, GAAST_F32, 0, "mfma32p tables n=10 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(10, gen10, GAAST_F64, 0, "mfma16x4 f64 tables n=10 general metric", "rescaled basis");
     }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {

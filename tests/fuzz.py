@@ -70,6 +70,10 @@ def random_big_program(seed):
     metric = [1.0] * n if rng.random() < 0.5 else [float(rng.choice([1.0, -1.0])) for _ in range(n)]
     if rng.random() < 0.25:
         metric[int(rng.integers(0, n))] = 0.0            # degenerate: general coefficients, CSR kernel
+    if rng.random() < 0.35:                               # general diagonal metric (algebra.rs:148-165): squares other than +-1
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(0, n))
+            metric[i] = metric[i] * float(rng.choice([2.0, 0.5, 3.0, 1.5, 0.25])) if metric[i] != 0.0 else 0.0
 
     def leaf():
         if rng.random() < 0.5:

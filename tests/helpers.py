@@ -178,7 +178,7 @@ def gp_bits(n, metric_diag, A, B, absolute=False):
     return np.bincount((a ^ b).ravel(), weights=terms.ravel(), minlength=N)
 
 
-def abs_terms_bound(n, A_bits, B_bits):
+def abs_terms_bound(n, A_bits, B_bits, metric=None):
     """sum over all blade pairs landing on each output blade of |A[a]| |B[b]| (the XOR-convolution of |A| and |B|) by a
     Walsh-Hadamard transform: O(n 2^n) instead of the 4^n table of gp_bits(absolute=True).  For metrics with entries
     of modulus <= 1 it bounds sum |term| from above (null vectors only remove terms)."""
@@ -191,7 +191,16 @@ def abs_terms_bound(n, A_bits, B_bits):
             h *= 2
         return v
     N = 1 << n
-    return np.abs(wht(wht(np.abs(A_bits)) * wht(np.abs(B_bits))) / N)
+    A_bits, B_bits = np.abs(np.asarray(A_bits, dtype=np.float64)), np.abs(np.asarray(B_bits, dtype=np.float64))
+    if metric is None:
+        return np.abs(wht(wht(A_bits) * wht(B_bits)) / N)
+    # general diagonal metric: |term| = |A_S| |B_U| prod_{i in S & U} |g_i| = (w_S |A_S|) (w_U |B_U|) / w_T with
+    # w_S = prod_{i in S} sqrt|g_i| (1 for a null vector, whose terms only vanish: still an upper bound)
+    w = np.ones(N)
+    for i, g in enumerate(metric):
+        if g != 0.0:
+            w = np.where((np.arange(N) >> i) & 1, w * np.sqrt(abs(float(g))), w)
+    return np.abs(wht(wht(A_bits * w) * wht(B_bits * w)) / N) / w
 
 
 # ---- C hosts and the test transport (tests/cpp) ---------------------------------------------------------------------

@@ -23,7 +23,7 @@ def _gp(n, left_grades=None):
     return build, lg
 
 
-def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
+def _check(n, metric, left_grades, variants, batch, seed, out_grades=None, eps_factor=4, exact_order_too=False):
     """variants: [(dtype, flags, expected launch-name prefix, HIP kernel)]; one oracle evaluation serves them all.  The launch
     label names the HIP kernel instantiation prepare_step picked ("<what> :: <kernel<...>>", the name rocprofv3 reports):
     the test asserts it, so a docstring cannot go stale about which kernel it covers."""
@@ -39,12 +39,17 @@ def _check(n, metric, left_grades, variants, batch, seed, out_grades=None):
         assert mask == wmask
         assert any(l.startswith(prefix) and l.split(" :: ")[-1].startswith(kernel) for l in spec.launches()), (prefix, kernel, spec.launches())
         eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+        general = any(m not in (1.0, -1.0, 0.0) for m in metric)
         for i in range(batch):
-            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, full_grades(n), rows64[1][i]))
-            bound = 4 * eps * bits_to_row(n, og, S) + 1e-300
+            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, full_grades(n), rows64[1][i]), metric if general else None)
+            bound = eps_factor * eps * bits_to_row(n, og, S) + 1e-300
             err = np.abs(got[i].astype(np.float64) - want[i])
             assert np.all(err <= bound), (prefix, dtype, i, float((err / bound).max()))
         assert np.abs(want).max() > 1.0     # a real product, not zeros
+    if exact_order_too:     # the reference's summation order stays available, bit for bit (k_product_csr: general coefficients)
+        got, mask, spec = hip_eval_batch(build, alg, rows64, batch, dtype=ga.F64, flags=ga.FLAG_EXACT_ORDER)
+        assert any("product_csr" in l for l in spec.launches()), spec.launches()
+        assert np.array_equal(got, want)
 
 
 def test_n10_f64_matrix_core_and_vector_kernels():
@@ -250,3 +255,43 @@ def test_negative_zero_operands_leave_no_trace(n, dtype):
     assert any("product_dense_mfma[" in l for l in spec.launches())
     assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
     assert not np.signbit(got[4]).any() and not np.signbit(got[5]).any() and not got[4].any()
+
+
+@pytest.mark.parametrize("metric", [[2.0, 0.5, -3.0, 1.0, 1.0, 1.0, 1.0, 1.0], [0.0, 7.5, -0.125, 1.0, 2.0, 2.0, -1.0, 3.0],
+                                    [1.5, -2.0, 0.3, 1.0, -1.0, 4.0, 1.0, 0.0, 2.5]])
+def test_general_diagonal_metrics_run_on_the_dense_kernels(metric):
+    """algebra.rs:148-165 (`impl MetricAlgebra for [f64; D]`) multiplies by ANY base_vec_dot (:79-81).  Round 2 sent every
+    entry other than +-1 / 0 to k_product_csr (2.2 M products/s at n = 8 against ~800 M/s).  Now the dense kernels run in the
+    rescaled basis f_i = e_i / sqrt|g_i|: operands times w_S while staged, result times 1 / w_T when stored (plan.cpp:
+    dense_scales_ok / blade_scale).  Bound: 8 eps sum|terms| per component -- the 4 eps of the +-1 case plus three roundings
+    per term (w_S A_S, w_U B_U, C'_T / w_T) and the roundings of the three factors themselves.  With GAAST_FLAG_EXACT_ORDER the
+    product stays on k_product_csr and is bit-exact."""
+    n = len(metric)
+    dg = "true" if 0.0 in metric else "false"
+    variants = [(ga.F32, 0, "product_dense_mfma[", f"k_gp_mfma16x4<float,{dg},{n},"), (ga.F64, 0, "product_dense_mfma[", f"k_gp_mfma16x4<double,{dg},{n},"),
+                (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<double,{dg},256,"), (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<float,{dg},256,")]
+    _check(n, metric, None, variants, batch=7, seed=300 + n, eps_factor=8, exact_order_too=True)
+
+
+def test_general_diagonal_metric_at_n12_and_partial_operands():
+    """a 12-dimensional general metric on the headline kernel (k_gp_mfma32p) and on k_gp_mfma16x4<double>, and at n = 10 with a
+    left operand that misses grades (the scale table follows the map, not the blade index)"""
+    metric = [1.0, 2.0, -0.5, 1.0, 3.0, 1.0, -1.0, 0.25, 1.0, 1.0, -4.0, 1.5]
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,12>"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,12,")],
+           batch=1, seed=312, eps_factor=8)
+    metric10 = [2.0, 1.0, -0.5, 1.0, 0.0, 1.0, -1.0, 0.25, 3.0, 1.0]
+    _check(10, metric10, [0, 1, 2, 3, 4, 5, 6, 7], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<true,10>"),
+                                                     (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,true,10,")], batch=2, seed=310, eps_factor=8)
+
+
+def test_a_metric_too_wild_to_rescale_stays_on_the_list_kernels():
+    """1e200 and 1e-200 among the squares: w_S would leave the range in which the rescaling is harmless (2^+-300 in f64,
+    2^+-40 in f32: plan.cpp dense_scales_ok) -> the exact kernels, bit-exact"""
+    metric = [1e200, 1e-200, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    build, lg = _gp(8)
+    rng = np.random.default_rng(5)
+    rows = {0: rows_of(8, lg, 2, rng), 1: rows_of(8, lg, 2, rng)}
+    want, _ = oracle_eval_batch(build, metric, rows, 2)
+    got, _, spec = hip_eval_batch(build, metric, rows, 2)
+    assert not any("product_dense" in l for l in spec.launches()), spec.launches()
+    assert np.array_equal(got, want)

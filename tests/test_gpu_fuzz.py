@@ -106,7 +106,7 @@ def test_random_big_programs_default_and_matrix_paths_stay_close():
     """the same big programs on the default plan (dense re-ordered kernels where they apply) in f64 and with the
     opt-in matrix-representation kernels in f32: not bit-exact by design -- checked against the oracle relative
     to the size of the terms (sum of |components| of the result is a cheap stand-in for a full error bound)."""
-    dense = spinor = 0
+    dense = spinor = rescaled = 0
     for seed in range(9000, 9024):
         n, metric, spec = random_big_program(seed)
         want = realise(spec, OracleBackend(), n).specialize(og.as_algebra(metric)).eval().to_dict()
@@ -114,6 +114,7 @@ def test_random_big_programs_default_and_matrix_paths_stay_close():
         hs = realise(spec, HipBackend(), n).specialize(metric)
         got = hs.eval().to_dict()
         dense += any("product_dense" in l for l in hs.launches())
+        rescaled += any("rescaled basis" in l for l in hs.launches())
         assert set(got) == set(want)
         for k in want:
             assert np.allclose(got[k], want[k], rtol=0, atol=1e-11 * scale * 4 ** n / 256), f"seed {seed} grade {k}\n{spec}"
@@ -122,4 +123,4 @@ def test_random_big_programs_default_and_matrix_paths_stay_close():
         spinor += any("product_spinor_gemm" in l for l in hs.launches())
         for k in want:
             assert np.allclose(got[k], want[k], rtol=0, atol=2e-4 * scale), f"seed {seed} grade {k} (f32)\n{spec}"
-    assert dense > 0 and spinor > 0, (dense, spinor)
+    assert dense > 0 and spinor > 0 and rescaled > 0, (dense, spinor, rescaled)   # general diagonal metrics reach the dense kernels too
