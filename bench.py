@@ -120,11 +120,20 @@ def workload_spec(name):
                     default_batch=1 << 22,
                     label="R^{4,1} rotor sandwich R X ~R with one shared rotor, f64")
     import re
-    m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order)
+    m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x|ee|eo|oe|oo)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order), gp12f32ee (even x even)
     if m:
         n, dt, var = int(m.group(1)), m.group(2), m.group(3)
         full = list(range(n + 1))
         sz = 4 if dt == "f32" else 8
+        if var in ("ee", "eo", "oe", "oo"):
+            # parity-pure operands (rotor composition, the second product of a sandwich): 2^(n-1) components each, a quarter of
+            # the 4^n table -- one product in the even subalgebra Cl(n - 1)
+            grades = {"e": [k for k in full if k % 2 == 0], "o": [k for k in full if k % 2 == 1]}
+            batch = max(64, min(1 << 22, (1 << 30) // ((1 << (n - 1)) * sz)))
+            names = {"e": "even", "o": "odd"}
+            return dict(n=n, metric=[1.0] * n, dtype=ga.F32 if dt == "f32" else ga.F64, dtname=dt, inputs=[grades[var[0]], grades[var[1]]],
+                        build=lambda a, b: a * b, entries=4 ** n // 4, default_batch=batch,
+                        label=f"R^{n} {names[var[0]]} x {names[var[1]]} geometric product ({1 << (n - 1)} components each, 4^{n}/4 table entries), {dt}")
         batch = max(64, min(1 << 22, (1 << 30) // ((1 << n) * sz)))          # 1 GiB per operand
         if var == "x":
             batch = max(64, batch >> 6)

@@ -291,8 +291,13 @@ struct BlockStep<double> {
 };
 
 // NEGLO: all four lo basis vectors square to -1 (else: all four to +1)
-template <typename T, bool DEGENERATE, int THREADS, bool NEGLO>
+template <typename T, bool DEGENERATE, int THREADS, bool NEGLO, bool SCALED = false>
 __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
+    // SCALED (a general diagonal metric, DenseArgs::left_scale ...): a separate instantiation, so that the +-1 / 0 kernels
+    // carry none of its code or registers
+    const T* const left_scale = SCALED ? p.left_scale : nullptr;
+    const T* const right_scale = SCALED ? p.right_scale : nullptr;
+    const T* const out_scale = SCALED ? p.out_scale : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int n = p.n;
@@ -322,9 +327,9 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
                 __syncthreads();
             }
             stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
+                                       p.canon_left, smem, item_stride, nitems, tid, left_scale);
             stage_operands<T, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, p.right_scale);
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, right_scale);
         }
         __syncthreads();
 
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
             // ---- scatter the 16 accumulators to their positions in the graded row ----
             T* orow = p.out + (item0 + it) * p.out_stride;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) store_result<T>(orow, om[i], acc.get(i), p.beta, p.out_scale, (c_hi << 4) + i);
+            for (int i = 0; i < 16; ++i) store_result<T>(orow, om[i], acc.get(i), p.beta, out_scale, (c_hi << 4) + i);
         }
         __syncthreads();  // the LDS image is rewritten by the next group
     }
@@ -404,8 +409,11 @@ __device__ __forceinline__ int mfma_b_pos(int m) {
     return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
 }
 
-template <bool DEGENERATE, int THREADS>
+template <bool DEGENERATE, int THREADS, bool SCALED = false>
 __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
+    const float* const left_scale = SCALED ? p.left_scale : nullptr;
+    const float* const right_scale = SCALED ? p.right_scale : nullptr;
+    const float* const out_scale = SCALED ? p.out_scale : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int n = p.n;
@@ -426,9 +434,9 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     }
     {
         stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
+                                       p.canon_left, smem, item_stride, nitems, tid, left_scale);
         stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, p.right_scale);
+                                       p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, right_scale);
     }
     __syncthreads();
 
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-            store_result<float>(orow, om[c_lo], acc[r], p.beta, p.out_scale, (c_hi << 5) + c_lo);
+            store_result<float>(orow, om[c_lo], acc[r], p.beta, out_scale, (c_hi << 5) + c_lo);
         }
     }
 }
@@ -563,8 +571,11 @@ __device__ __forceinline__ constexpr int mfma16_k(int t) {
 // current one; barriers between the phases wait for LDS traffic only (lds_barrier).
 // (The second launch bound, two workgroups per CU, only changes the compiler's scheduling here -- every instantiation
 //  stays under the 256 registers of two waves per SIMD anyway: n = 10 / 11 gain 7-9 % with it, n = 12 LOSES 6 %.)
-template <bool DEGENERATE, int NDIM>
+template <bool DEGENERATE, int NDIM, bool SCALED = false>
 __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_gp_mfma32p(DenseArgs<float> p) {
+    const float* const left_scale = SCALED ? p.left_scale : nullptr;
+    const float* const right_scale = SCALED ? p.right_scale : nullptr;
+    const float* const out_scale = SCALED ? p.out_scale : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
     static_assert(MPR * ROWS == 8, "eight 16-byte pieces per thread and group");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
-    const bool fast = p.left_contig && p.right_contig && p.left_full && p.right_full && !p.left_scale;   // (a rescaled basis: general staging)
+    const bool fast = !SCALED && p.left_contig && p.right_contig && p.left_full && p.right_full;   // (a rescaled basis: general staging)
 
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
 
@@ -704,9 +715,9 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                 lds_barrier<THREADS>();
             }
             stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                           p.canon_left, smem, item_stride, nitems, tid, p.left_scale);
+                                           p.canon_left, smem, item_stride, nitems, tid, left_scale);
             stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid, p.right_scale);
+                                           p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid, right_scale);
             lds_barrier<THREADS>();
             constexpr int quads_per_item = N >> 1;        // 16-byte pieces of +A and +B together
             for (int e = tid; e < nitems * quads_per_item; e += THREADS) {
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c_lo = (r & 3) + 8 * (r >> 2) + 4 * h;
-                store_result<float>(orow, om[c_lo], acc[r], p.beta, p.out_scale, (c_hi << 5) + c_lo);
+                store_result<float>(orow, om[c_lo], acc[r], p.beta, out_scale, (c_hi << 5) + c_lo);
             }
         }
         lds_barrier<THREADS>();   // the images are rewritten by the next group
@@ -925,9 +936,13 @@ struct Mfma16x4<float> {
 // into +0.0, and in these kernels a zero operand of either sign contributes +-0 to a sum that starts from +0.0 and is
 // rounded to nearest, which leaves every sum -- also an all-zero one: (+0) + (-0) = +0 -- bit for bit what it would be
 // (tests/test_gpu_dense_oracle.py::test_negative_zero_operands_leave_no_trace).
-template <typename T, bool DEGENERATE, int NDIM, int MODE>
+template <typename T, bool DEGENERATE, int NDIM, int MODE, bool SCALED = false>
 __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p) {
     constexpr bool FAST = MODE >= 1;
+    static_assert(!(SCALED && MODE != 0), "a rescaled basis runs on the general staging and stores");
+    const T* const left_scale = SCALED ? p.left_scale : nullptr;
+    const T* const right_scale = SCALED ? p.right_scale : nullptr;
+    const T* const out_scale = SCALED ? p.out_scale : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     lds_u8* lds = (lds_u8*)smem_raw;
@@ -1018,7 +1033,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
         ook[r] = w >= 0;
         ooff[r] = uint32_t(w & 0x3fffffff) << ES;
         osg[r] = (uint32_t(w) & 0x40000000u) << 1;
-        osc[r] = (MODE <= 1 && p.out_scale) ? p.out_scale[(c_hi << 4) + MM::row(kq, r)] : T(1);
+        osc[r] = (SCALED && out_scale) ? out_scale[(c_hi << 4) + MM::row(kq, r)] : T(1);
     }
 
     // FAST: byte address inside the +A / +B image and negate bit of the thread's four components per row
@@ -1074,9 +1089,9 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                 lds_barrier<THREADS>();
             }
             stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem + A_EL, item_stride, 1, tid, p.left_scale);
+                                       p.canon_left, smem + A_EL, item_stride, 1, tid, left_scale);
             stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
-                                       p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid, p.right_scale);
+                                       p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid, right_scale);
             lds_barrier<THREADS>();
             for (int e = tid; e < 2 * N; e += THREADS) {   // the negated images: -B N further, -A N + PAD_A further
                 if (e < N) smem[B_EL + N + e] = -smem[B_EL + e];
@@ -1192,7 +1207,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                 if (ook[r]) {
                     T* q = reinterpret_cast<T*>(orow + ooff[r]);
                     T v = acc[r];
-                    if (p.out_scale) v = v * osc[r];       // back from the rescaled basis
+                    if (SCALED) v = v * osc[r];            // back from the rescaled basis
                     v = MM::flip(v, osg[r]);
                     if (osg[r] && !p.beta) v = T(0) + v;   // a zero result stays +0.0 under a negated reordering sign
                     *q = p.beta ? *q + v : v;

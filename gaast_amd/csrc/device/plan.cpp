@@ -359,7 +359,7 @@ struct Lowering {
         if (nd.product_kind == GAAST_PROD_GEOMETRIC) return true;
         if (nd.product_kind != GAAST_PROD_EXPLICIT || !nd.comp_muls) return false;
         const int n = d.vec_space_dim;
-        if (n < 6 || double(nd.n_comp_muls) * 8.0 < double(uint64_t(1) << (2 * n))) return false;
+        if (n < 6 || double(nd.n_comp_muls) * 32.0 < double(uint64_t(1) << (2 * n))) return false;   // (4^(n-1) / 8: parity-pure products)
         const uint64_t lmin = node(nd.child0).minimal_grade_mask, rmin = node(nd.child1).minimal_grade_mask;
         auto contribs = iter_contribs(nd.minimal_grade_mask, Selection{GAAST_PROD_GEOMETRIC, nullptr, nullptr}, lmin, rmin);
         if (comp_mul_count(n, contribs) != nd.n_comp_muls) return false;
@@ -372,16 +372,32 @@ struct Lowering {
         return same;
     }
 
+    // The algebra a dense kernel runs in: the program's (n, metric), or -- for a product of parity-pure operands -- the
+    // even subalgebra Cl+(p, q) = Cl(n - 1) built on a pivot vector e_p (parity_reduced_frame below).
+    struct DenseFrame {
+        int n = 0;
+        std::vector<double> metric;
+        int pivot = -1;            // >= 0: parity-reduced; the basis vector of the program's algebra the reduction is built on
+        int lpar = -1, rpar = -1;  // parity of the left / right operand (0 even, 1 odd) when reduced
+    };
+    static int parity_of(uint64_t mask) {   // 0: only even grades, 1: only odd grades, -1: mixed or empty
+        const uint64_t EVEN = 0x5555555555555555ULL;
+        if (!mask) return -1;
+        if (!(mask & ~EVEN)) return 0;
+        if (!(mask & EVEN)) return 1;
+        return -1;
+    }
+
     // Basis permutation that brings a diagonal metric into the shape the dense kernels want: position j of the
     // permuted basis holds original vector perm[j]; positions [0, L) (the "lo" bits of a blade) hold vectors that
     // square to +-1 (+1 first), never 0.  uniform: the four lo vectors must all square to the same sign (vector-FMA
     // kernel: compile-time sign pattern).  The identity is kept whenever it already qualifies.
-    bool dense_basis_permutation(int L, bool uniform, std::vector<int>& perm) const {
-        const int n = d.vec_space_dim;
-        std::vector<int> plus, minus;   // by the SIGN of the square: a general entry g is rescaled to g / |g| (dense_scales)
+    static bool dense_basis_permutation(const DenseFrame& f, int L, bool uniform, std::vector<int>& perm) {
+        const int n = f.n;
+        std::vector<int> plus, minus;   // by the SIGN of the square: a general entry g is rescaled to g / |g| (blade_scale)
         for (int i = 0; i < n; ++i) {
-            if (d.metric_diag[i] > 0.0) plus.push_back(i);
-            if (d.metric_diag[i] < 0.0) minus.push_back(i);
+            if (f.metric[size_t(i)] > 0.0) plus.push_back(i);
+            if (f.metric[size_t(i)] < 0.0) minus.push_back(i);
         }
         std::vector<int> lo;
         if (uniform) {
@@ -410,57 +426,114 @@ struct Lowering {
     // three more roundings per term than the +-1 / 0 case (the factors themselves are rounded once, from long double).
     // Used only when every w_S and 1 / w_S stays within 2^+-40 (f32) / 2^+-300 (f64) -- no overflow or gradual underflow
     // introduced by the rescaling for operands of ordinary magnitude; otherwise the exact list kernels keep the product.
-    bool metric_is_unit() const {
-        for (int i = 0; i < d.vec_space_dim; ++i) {
-            const double g = d.metric_diag[i];
+    static bool metric_is_unit(const DenseFrame& f) {
+        for (double g : f.metric)
             if (g != 1.0 && g != -1.0 && g != 0.0) return false;
-        }
         return true;
     }
-    bool dense_scales_ok() const {
-        if (metric_is_unit()) return true;
+    bool dense_scales_ok(const DenseFrame& f) const {
         long double up = 1.0L, down = 1.0L;
-        for (int i = 0; i < d.vec_space_dim; ++i) {
-            const double g = d.metric_diag[i];
+        for (double g : f.metric) {
             if (!(g == g) || g == 1.0 / 0.0 || g == -1.0 / 0.0) return false;
             if (g == 0.0) continue;
             const long double r = sqrtl(fabsl((long double)g));
             if (r > 1.0L) up *= r;
             else down *= r;
         }
+        if (f.pivot >= 0) {   // the reduction's own factors are powers of 1 / g_p up to (n - 1) / 2, and g_p itself
+            const long double gp = fabsl((long double)d.metric_diag[f.pivot]);
+            const long double worst = powl(gp > 1.0L ? gp : 1.0L / gp, (long double)((d.vec_space_dim + 1) / 2));
+            up *= worst;
+            down /= worst;
+        }
+        if (metric_is_unit(f) && (f.pivot < 0 || fabs(d.metric_diag[f.pivot]) == 1.0)) return true;
         const long double lim = plan.dtype == GAAST_F32 ? 0x1p40L : 0x1p300L;
         return up <= lim && down >= 1.0L / lim;
     }
-    long double blade_scale(uint32_t S) const {   // w_S
+    static long double blade_scale(const DenseFrame& f, uint32_t S) {   // w_S in the frame's algebra
         long double w = 1.0L;
-        for (int i = 0; i < d.vec_space_dim; ++i)
-            if (((S >> i) & 1u) && d.metric_diag[i] != 0.0) w *= sqrtl(fabsl((long double)d.metric_diag[i]));
+        for (int i = 0; i < f.n; ++i)
+            if (((S >> i) & 1u) && f.metric[size_t(i)] != 0.0) w *= sqrtl(fabsl((long double)f.metric[size_t(i)]));
         return w;
     }
 
-    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>) and in which basis
-    int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm) const {
+    // Parity-pure operands (the reference only ever multiplies the entries it needs, specialize.rs:162-183; even x even --
+    // rotor composition, the second product of every sandwich -- needs a quarter of the 4^n table).  The even subalgebra
+    // Cl+ of Cl(n) is a Clifford algebra of dimension n - 1 on the generators f_i = e_i e_p (i != p, e_p any non-null basis
+    // vector): f_i f_j = -f_j f_i, f_i^2 = -g_i g_p.  An even blade e_E is a multiple of the f-blade on E \ {p},
+    //     e_E = c(E) f_{E \ p},   c(E) = sigma(E) (-g_p)^(-floor(|E \ p| / 2)),   sigma(E) = (-1)^#{i in E : i > p} if p in E, else 1
+    // and an odd multivector is (even) e_p:  A = A~ e_p,  A~_{S ^ p} = A_S tau(S) (p in S ? 1 : 1 / g_p),  tau(S) = (-1)^#{i in S : i > p}.
+    // With X^ = e_p X e_p^-1 (even X: the blades containing p change sign):
+    //     even x even: A B                      odd x even: (A~ B^) e_p
+    //     even x odd : (A B~) e_p               odd x odd : g_p A~ B~^
+    // Every case is ONE product of two elements of Cl(n - 1) -- 4^(n-1) multiply-adds -- with per-component factors on the
+    // way in and on the way out: exactly what the operand maps (position, negate bit, scale) and the result map carry.
+    bool parity_reduced_frame(uint64_t lmask, uint64_t rmask, DenseFrame& f) const {
+        const int n = d.vec_space_dim;
+        const int lp = parity_of(lmask), rp = parity_of(rmask);
+        if (lp < 0 || rp < 0 || n - 1 < 6) return false;
+        int p = -1;
+        for (int i = n - 1; i >= 0 && p < 0; --i)
+            if (d.metric_diag[i] != 0.0) p = i;
+        if (p < 0) return false;
+        f.n = n - 1;
+        f.metric.clear();
+        for (int i = 0; i < n; ++i)
+            if (i != p) f.metric.push_back(-d.metric_diag[i] * d.metric_diag[p] == 0.0 ? 0.0 : -d.metric_diag[i] * d.metric_diag[p]);
+        f.pivot = p;
+        f.lpar = lp;
+        f.rpar = rp;
+        return true;
+    }
+
+    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>), in which algebra
+    // (frame) and in which basis of it (perm)
+    int dense_kind_for(const DenseFrame& f, uint64_t n_comp_muls, std::vector<int>& perm) const {
+        const int n = f.n;
+        if (n < 6 || n > 14) return 0;  // small algebras: the exact kernel is HBM-bound anyway
+        // A general diagonal metric (algebra.rs:148-165 multiplies by ANY base_vec_dot, :79-81) runs in the rescaled basis
+        // f_i = e_i / sqrt|g_i|; it needs finite, well-scaled factors, else the list kernels keep the product
+        if (!dense_scales_ok(f)) return 0;
+        if (double(n_comp_muls) * 8.0 < double(uint64_t(1) << (2 * n))) return 0;  // the tiled kernels always do 4^n multiply-adds
+        const bool mfma_ok = plan.dtype == GAAST_F32 && !(plan.flags & GAAST_FLAG_NO_MFMA);
+        // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (lo = 4 bits)
+        if (mfma_ok && n >= 10 && dense_basis_permutation(f, 5, false, perm)) return 3;
+        if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
+        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(f, 4, false, perm)) return 4;   // k_gp_mfma16x4<float>
+        // f64 (the reference's value type), n = 8 ... 12: v_mfma_f64_16x16x4_f64, one item per workgroup
+        if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 12 &&
+            dense_basis_permutation(f, 4, false, perm))
+            return 4;
+        if (dense_basis_permutation(f, 4, true, perm)) return 1;
+        return 0;
+    }
+    int dense_choice(const gaast_node_desc& nd, BufRef res, BufRef l, BufRef r, std::vector<int>& perm, DenseFrame& frame) const {
         if (plan.flags & (GAAST_FLAG_EXACT_ORDER | GAAST_FLAG_NO_FUSION)) return 0;
         const int n = d.vec_space_dim;
-        if (n < 6 || n > 14) return 0;  // small algebras: the exact kernel is HBM-bound anyway
+        if (n < 6 || n > 15) return 0;
         if (layout(res).dim != n || layout(l).dim != n || layout(r).dim != n) return 0;
-        // A general diagonal metric (algebra.rs:148-165 multiplies by ANY base_vec_dot, :79-81) runs in the rescaled basis
-        // f_i = e_i / sqrt|g_i| (dense_scales); it needs finite, well-scaled factors, else the list kernels keep the product
-        if (!dense_scales_ok()) return 0;
-        const double full = double(uint64_t(1) << (2 * n));
-        if (double(nd.n_comp_muls) * 8.0 < full) return 0;  // the tiled kernels always do 4^n multiply-adds
-        if (!is_geometric_list(nd)) return 0;
-        const bool mfma_ok = plan.dtype == GAAST_F32 && !(plan.flags & GAAST_FLAG_NO_MFMA);
-        // matrix-core variants: f32, n >= 10 (32 result columns per wave, five lo vectors) / n = 8, 9 (four items per wave)
-        if (mfma_ok && n >= 10 && dense_basis_permutation(5, false, perm)) return 3;
-        if (n == 14) return 0;          // both operands of an item (128 KiB in f32) fit the LDS of the matrix-core kernel only
-        if (mfma_ok && (n == 8 || n == 9) && dense_basis_permutation(4, false, perm)) return 4;   // k_gp_mfma16x4<float>
-        // f64 (the reference's value type), n = 8, 9: v_mfma_f64_16x16x4_f64, one item per workgroup (at n = 10 the kernel
-        // exists and is correct but measures the same as the vector form: 22.3 M products/s either way)
-        if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 12 &&
-            dense_basis_permutation(4, false, perm))
-            return 4;
-        if (dense_basis_permutation(4, true, perm)) return 1;
+        const uint64_t lmask = node(nd.child0).minimal_grade_mask & layout(l).mask, rmask = node(nd.child1).minimal_grade_mask & layout(r).mask;
+        int kind = 0;
+        bool geometric_known = false, geometric = false;
+        auto is_gp = [&]() {
+            if (!geometric_known) {
+                geometric = is_geometric_list(nd);
+                geometric_known = true;
+            }
+            return geometric;
+        };
+        DenseFrame reduced;
+        if (parity_reduced_frame(lmask, rmask, reduced) && (kind = dense_kind_for(reduced, nd.n_comp_muls, perm)) && is_gp()) {
+            frame = reduced;
+            return kind;
+        }
+        DenseFrame full;
+        full.n = n;
+        full.metric.assign(d.metric_diag, d.metric_diag + n);
+        if (n <= 14 && (kind = dense_kind_for(full, nd.n_comp_muls, perm)) && is_gp()) {
+            frame = full;
+            return kind;
+        }
         return 0;
     }
 
@@ -585,40 +658,47 @@ struct Lowering {
             }
         }
         std::vector<int> perm;
-        if (const int dense_kind = dense_choice(nd, res, l, r, perm)) {
+        DenseFrame frame;
+        if (const int dense_kind = dense_choice(nd, res, l, r, perm, frame)) {
             if ((omin & lr.mask) != omin) {
                 fail(GAAST_ERR_MISSING_GRADE, "product result grade absent from result buffer");
                 return;
             }
-            const bool beta0 = is_fresh && (lr.mask & ~omin) == 0;
+            const int n = d.vec_space_dim;   // the program's algebra: graded rows, blade <-> (grade, index)
+            const int n2 = frame.n;          // the kernel's algebra: n, or n - 1 for parity-pure operands
+            const bool reduced = frame.pivot >= 0;
+            // grades this step produces: a parity-pure product fills only the grades of its own parity
+            uint64_t prod_mask = omin;
+            if (reduced) prod_mask &= ((frame.lpar ^ frame.rpar) ? 0xAAAAAAAAAAAAAAAAULL : 0x5555555555555555ULL);
+            const bool beta0 = is_fresh && (lr.mask & ~prod_mask) == 0;
             if (beta0) {
                 removed[size_t(fr->second)] = 1;
             }
-            Step& s = emit(Step::PRODUCT_DENSE, res, "product_dense[gp n=" + std::to_string(d.vec_space_dim) + "]");
+            Step& s = emit(Step::PRODUCT_DENSE, res, "product_dense[gp n=" + std::to_string(n) + "]");
             s.a = l;
             s.b = r;
             s.canon_a = canon_l;
             s.canon_b = canon_r;
             s.beta = beta0 ? 0 : 1;
             s.n_entries = nd.n_comp_muls;
-            const int n = d.vec_space_dim;
+            s.dense_n = n2;
             s.use_mfma = dense_kind == 3;
             s.use_mfma16 = dense_kind == 4;
             s.use_mfma16d = dense_kind == 4;
             s.mfma16_quads = dense_kind == 4 && plan.dtype == GAAST_F32;   // k_gp_mfma16x4<float>: B words in 16-byte quads
-            s.mfma32_pairs = dense_kind == 3 && n <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
-            // blade S of the program's basis <-> blade S' of the permuted basis, e_S = sign(S) e'_S' (the parity of the
-            // inversions of the new positions of S's vectors taken in ascending original order)
-            std::vector<int> inv(size_t(n), 0);
+            s.mfma32_pairs = dense_kind == 3 && n2 <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
+            // blade R of the frame's basis <-> blade R' of its permuted basis, f_R = sign(R) f'_R' (the parity of the
+            // inversions of the new positions of R's vectors taken in ascending original order)
+            std::vector<int> inv(size_t(n2), 0);
             bool identity = true;
-            for (int j = 0; j < n; ++j) {
+            for (int j = 0; j < n2; ++j) {
                 inv[size_t(perm[size_t(j)])] = j;
                 identity = identity && perm[size_t(j)] == j;
             }
-            std::vector<uint32_t> new_blade(size_t(1) << n), blade_sign(size_t(1) << n);
-            for (uint32_t S = 0; S < (1u << n); ++S) {
+            std::vector<uint32_t> new_blade(size_t(1) << n2), blade_sign(size_t(1) << n2);
+            for (uint32_t S = 0; S < (1u << n2); ++S) {
                 uint32_t S2 = 0, par = 0;
-                for (int p = 0; p < n; ++p) {
+                for (int p = 0; p < n2; ++p) {
                     if (!((S >> p) & 1u)) continue;
                     const int q = inv[size_t(p)];
                     par ^= uint32_t(__builtin_popcount(S2 >> (q + 1))) & 1u;
@@ -627,6 +707,48 @@ struct Lowering {
                 new_blade[S] = S2;
                 blade_sign[S] = par;
             }
+            // ---- stage 1: blade of the program's algebra -> blade of the frame's algebra, with a factor ----
+            const int pv = frame.pivot;
+            const long double gp = reduced ? (long double)d.metric_diag[pv] : 1.0L;
+            auto has_p = [&](uint32_t S) { return ((S >> pv) & 1u) != 0; };
+            auto tau = [&](uint32_t S) -> long double { return (__builtin_popcount(S >> (pv + 1)) & 1) ? -1.0L : 1.0L; };
+            auto compress = [&](uint32_t E) -> uint32_t {   // drop bit p
+                E &= ~(1u << pv);
+                return (E & ((1u << pv) - 1u)) | ((E >> (pv + 1)) << pv);
+            };
+            auto c_of = [&](uint32_t E) -> long double {    // e_E = c(E) f_{E \ p} for an even blade E
+                const int k = __builtin_popcount(E & ~(1u << pv));
+                long double v = powl(-1.0L / gp, (long double)(k / 2));
+                return has_p(E) ? v * tau(E) : v;
+            };
+            auto t_of = [&](uint32_t S) -> long double { return tau(S) * (has_p(S) ? 1.0L : 1.0L / gp); };   // odd S: A~_{S ^ p} = A_S t(S)
+            // operand component on blade S -> (frame blade R, factor): image value = A_S * factor
+            auto operand_to_frame = [&](uint32_t S, bool right, long double* factor) -> uint32_t {
+                if (!reduced) {
+                    *factor = 1.0L;
+                    return S;
+                }
+                const int par = right ? frame.rpar : frame.lpar;
+                const uint32_t E = par ? S ^ (1u << pv) : S;
+                long double f = (par ? t_of(S) : 1.0L) * c_of(E);
+                if (right && frame.lpar == 1 && has_p(E)) f = -f;   // the conjugation e_p X e_p^-1 of the right operand
+                *factor = f;
+                return compress(E);
+            };
+            // result component on blade T <- (frame blade R, factor): C_T = C'_R * factor
+            auto result_from_frame = [&](uint32_t T, long double* factor) -> uint32_t {
+                if (!reduced) {
+                    *factor = 1.0L;
+                    return T;
+                }
+                if ((frame.lpar ^ frame.rpar) == 0) {
+                    *factor = ((frame.lpar == 1) ? gp : 1.0L) / c_of(T);
+                    return compress(T);
+                }
+                const uint32_t E = T ^ (1u << pv);   // C = P e_p: C_{E ^ p} = P_E tau(E) (p in E ? g_p : 1)
+                *factor = tau(E) * (has_p(E) ? gp : 1.0L) / c_of(E);
+                return compress(E);
+            };
             // position of blade m in the LDS image the kernel reads (mirrors kernels.hip.hpp)
             auto vec_pos = [](uint32_t m) {  // dense_lds_pos
                 const uint32_t x = m >> 4, lo = m & 15;
@@ -657,17 +779,20 @@ struct Lowering {
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
                 return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
             };
-            // entry: row offset | image position << 16 | (negate while staging) << 31
+            // entry: row offset | image position << 16 | (negate while staging) << 31; scale[entry] = |factor| (when any != 1)
             auto build_map = [&](const Layout& lay, uint64_t want, uint64_t flip, bool right, std::vector<uint32_t>& map,
-                                 int* full, int* contig) {
+                                 std::vector<double>& scale, int* full, int* contig) {
                 bool seq = true;
                 for (int k = 0; k <= n; ++k) {
                     if (!((want >> k) & 1ULL)) continue;
                     for (uint32_t i = 0; i < bt.grade_dim[size_t(k)]; ++i) {
                         const uint32_t orig = bt.blade_of[size_t(k)][i];
-                        const uint32_t blade = new_blade[orig];
-                        uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ blade_sign[orig];
-                        // k_gp_mfma16: the b_hi part of (-1)^(|a_hi| |b_lo|), |a_hi| = |b_hi| + |c_hi| (mod 2), lives in the B image
+                        long double f1;
+                        const uint32_t R = operand_to_frame(orig, right, &f1);
+                        const uint32_t blade = new_blade[R];
+                        const long double factor = f1 * blade_scale(frame, R);
+                        uint32_t neg = uint32_t((flip >> k) & 1ULL) ^ blade_sign[R] ^ (factor < 0.0L ? 1u : 0u);
+                        // image-pair kernels: the b_hi part of (-1)^(|a_hi| |b_lo|), |a_hi| = |b_hi| + |c_hi| (mod 2), lives in the B image
                         if (s.use_mfma16 && right) neg ^= uint32_t(__builtin_popcount(blade >> 4) & __builtin_popcount(blade & 15u) & 1);
                         if (s.mfma32_pairs && right) neg ^= uint32_t(__builtin_popcount(blade >> 5) & __builtin_popcount(blade & 31u) & 1);
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
@@ -678,34 +803,45 @@ struct Lowering {
                         const uint32_t off = uint32_t(lay.offset(k) + i);
                         seq = seq && off == map.size();
                         map.push_back(off | (pos << 16) | sgn);
-                        if (s.scaled) (right ? s.coeff_b : s.coeff).push_back(double(blade_scale(orig)));
+                        scale.push_back(double(fabsl(factor)));
                     }
                 }
-                *full = map.size() == (size_t(1) << n);
+                *full = map.size() == (size_t(1) << n2);
                 *contig = seq && map.size() % 4 == 0 && !map.empty();
             };
-            s.scaled = metric_is_unit() ? 0 : 1;
-            build_map(ll, lmin & ll.mask, flip_l, false, s.u32_a, &s.left_full, &s.left_contig);
-            build_map(lrr, rmin & lrr.mask, flip_r, true, s.u32_b, &s.right_full, &s.right_contig);
-            // out_map: indexed by the blade of the permuted basis; offset | reordering sign << 30, or -1
-            s.i32_a.assign(size_t(1) << n, -1);
+            uint64_t lwant = lmin & ll.mask, rwant = rmin & lrr.mask;
+            build_map(ll, lwant, flip_l, false, s.u32_a, s.coeff, &s.left_full, &s.left_contig);
+            build_map(lrr, rwant, flip_r, true, s.u32_b, s.coeff_b, &s.right_full, &s.right_contig);
+            // out_map: indexed by the blade of the frame's permuted basis; offset | sign << 30, or -1; coeff_c: |factor|
+            s.i32_a.assign(size_t(1) << n2, -1);
+            s.coeff_c.assign(size_t(1) << n2, 1.0);
             for (uint32_t m = 0; m < (1u << n); ++m) {
                 const int g = __builtin_popcount(m);
-                if ((omin >> g) & 1ULL)
-                    s.i32_a[new_blade[m]] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (blade_sign[m] << 30));
+                if (!((prod_mask >> g) & 1ULL)) continue;
+                long double f1;
+                const uint32_t R = result_from_frame(m, &f1);
+                const long double factor = f1 / blade_scale(frame, R);
+                const uint32_t sgn = blade_sign[R] ^ (factor < 0.0L ? 1u : 0u);
+                s.i32_a[new_blade[R]] = int32_t(uint32_t(lr.offset(g) + bt.index_of[m]) | (sgn << 30));
+                s.coeff_c[new_blade[R]] = double(fabsl(factor));
+            }
+            // scale tables only when some factor is not 1 (a general metric): +-1 / 0 metrics keep the register-prefetch paths
+            s.scaled = 0;
+            for (const std::vector<double>* v : {&s.coeff, &s.coeff_b, &s.coeff_c})
+                for (double x : *v) s.scaled |= int(x != 1.0);
+            if (!s.scaled) {
+                s.coeff.clear();
+                s.coeff_b.clear();
+                s.coeff_c.clear();
             }
             // every blade produced into a row that holds nothing else: whole rows can be written in 16-byte pieces
-            s.out_full = lr.row_len == (int64_t(1) << n);
-            for (uint32_t m = 0; m < (1u << n); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
-            if (s.scaled) {
-                s.coeff_c.assign(size_t(1) << n, 0.0);
-                for (uint32_t m = 0; m < (1u << n); ++m) s.coeff_c[new_blade[m]] = double(1.0L / blade_scale(m));
-            }
+            s.out_full = lr.row_len == (int64_t(1) << n2);
+            for (uint32_t m = 0; m < (1u << n2); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
             for (uint32_t w : s.u32_a) s.left_signs |= int(w >> 31);
             for (int32_t w : s.i32_a) s.out_signs |= int(w >= 0 && (uint32_t(w) & 0x40000000u));
             const int lo_bits = s.use_mfma ? 5 : 4;
-            for (int j = 0; j < n; ++j) {
-                const double g = d.metric_diag[perm[size_t(j)]];   // only its sign matters here: the magnitude is in the scales
+            for (int j = 0; j < n2; ++j) {
+                const double g = frame.metric[size_t(perm[size_t(j)])];   // only its sign matters here: the magnitude is in the scales
                 if (j < lo_bits) {
                     if (g < 0.0) s.neg_lo |= 1u << j;
                 } else {
@@ -715,7 +851,9 @@ struct Lowering {
             }
             s.neg_lo_all = dense_kind == 1 && s.neg_lo == 15u;
             s.degenerate = s.zero_hi != 0;
+            static const char* const par_name[2] = {"even", "odd"};
             s.name = std::string(dense_kind == 1 ? "product_dense" : "product_dense_mfma") + "[gp n=" + std::to_string(n) +
+                     (reduced ? std::string(" ") + par_name[frame.lpar] + " x " + par_name[frame.rpar] + " in Cl(" + std::to_string(n2) + ")" : std::string()) +
                      (identity ? "" : " permuted basis") + (s.scaled ? " rescaled basis" : "") + "]";
             touch(res);
             return;

@@ -74,6 +74,7 @@ struct Step {
     uint32_t neg_lo = 0;   // lo basis vectors (of the permuted basis) that square to -1
     int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)
     int degenerate = 0;
+    int dense_n = 0;     // DENSE: dimension of the algebra the kernel runs in (the program's n, or n - 1: parity-pure operands)
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)

@@ -250,22 +250,31 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                     s.lds = (size_t(s.items_per_block) * size_t(4 << n) + 16) * sizeof(float);
                     if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
                     using KernD = void (*)(DenseArgs<float>);
-                    const KernD kernp = n == 10   ? (s.degenerate ? &k_gp_mfma32p<true, 10> : &k_gp_mfma32p<false, 10>)
-                                        : n == 11 ? (s.degenerate ? &k_gp_mfma32p<true, 11> : &k_gp_mfma32p<false, 11>)
-                                        : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12> : &k_gp_mfma32p<false, 12>)
-                                                  : (s.degenerate ? &k_gp_mfma32p<true, 13> : &k_gp_mfma32p<false, 13>);
+                    auto pickp = [&](auto sc) -> KernD {
+                        constexpr bool SC = decltype(sc)::value;
+                        return n == 10   ? (s.degenerate ? &k_gp_mfma32p<true, 10, SC> : &k_gp_mfma32p<false, 10, SC>)
+                               : n == 11 ? (s.degenerate ? &k_gp_mfma32p<true, 11, SC> : &k_gp_mfma32p<false, 11, SC>)
+                               : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12, SC> : &k_gp_mfma32p<false, 12, SC>)
+                                         : (s.degenerate ? &k_gp_mfma32p<true, 13, SC> : &k_gp_mfma32p<false, 13, SC>);
+                    };
+                    const KernD kernp = s.scaled ? pickp(std::true_type{}) : pickp(std::false_type{});
                     s.kern[0] = reinterpret_cast<const void*>(kernp);
-                    s.hip_kernel = "k_gp_mfma32p<" + dg + "," + std::to_string(n) + ">";
+                    s.hip_kernel = "k_gp_mfma32p<" + dg + "," + std::to_string(n) + (s.scaled ? ",true>" : ">");
                     if (int st = allow_lds(s.kern[0], s.lds)) return st;
                     return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
                 }
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
-                auto kern = s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256> : &k_gp_mfma32<false, 256>)
-                            : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512> : &k_gp_mfma32<false, 512>)
-                                               : (s.degenerate ? &k_gp_mfma32<true, 1024> : &k_gp_mfma32<false, 1024>);   // n = 14: 16 waves, 128 KiB of LDS
+                using KernD = void (*)(DenseArgs<float>);
+                auto pick32 = [&](auto sc) -> KernD {
+                    constexpr bool SC = decltype(sc)::value;
+                    return s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256, SC> : &k_gp_mfma32<false, 256, SC>)
+                           : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512, SC> : &k_gp_mfma32<false, 512, SC>)
+                                              : (s.degenerate ? &k_gp_mfma32<true, 1024, SC> : &k_gp_mfma32<false, 1024, SC>);   // n = 14: 16 waves, 128 KiB of LDS
+                };
+                const KernD kern = s.scaled ? pick32(std::true_type{}) : pick32(std::false_type{});
                 s.kern[0] = reinterpret_cast<const void*>(kern);
-                s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + ">";
+                s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + (s.scaled ? ",true>" : ">");
                 return allow_lds(s.kern[0], s.lds);
             }
         }
@@ -288,12 +297,21 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
                 }
             };
-            const KernD kd = pick(std::integral_constant<int, 0>{}), kf = pick(std::integral_constant<int, 1>{}),
+            auto pick_scaled = [&]() -> KernD {   // a rescaled basis (general diagonal metric): general staging and stores only
+                switch (n) {
+                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, 0, true> : &k_gp_mfma16x4<T, false, 8, 0, true>;
+                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, 0, true> : &k_gp_mfma16x4<T, false, 9, 0, true>;
+                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, 0, true> : &k_gp_mfma16x4<T, false, 10, 0, true>;
+                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, 0, true> : &k_gp_mfma16x4<T, false, 11, 0, true>;
+                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, 0, true> : &k_gp_mfma16x4<T, false, 12, 0, true>;
+                }
+            };
+            const KernD kd = s.scaled ? pick_scaled() : pick(std::integral_constant<int, 0>{}), kf = pick(std::integral_constant<int, 1>{}),
                         kw = pick(std::integral_constant<int, 2>{});
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
             s.kern[2] = reinterpret_cast<const void*>(kw);
-            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + ",0|1|2>";   // staging / store mode: by alignment at launch
+            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + (s.scaled ? ",0,true>" : ",0|1|2>");   // staging / store mode: by alignment at launch
             for (int v = 0; v < 3; ++v)
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
@@ -305,15 +323,17 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         if (s.lds > g_max_lds)
             return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product of dimension " + std::to_string(n) + " does not fit in LDS");
         using KernD = void (*)(DenseArgs<T>);
-        KernD kern;
-        if (s.neg_lo_all)
-            kern = s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, true> : &k_gp_dense<T, false, 256, true>)
-                                    : (s.degenerate ? &k_gp_dense<T, true, 512, true> : &k_gp_dense<T, false, 512, true>);
-        else
-            kern = s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false> : &k_gp_dense<T, false, 256, false>)
-                                    : (s.degenerate ? &k_gp_dense<T, true, 512, false> : &k_gp_dense<T, false, 512, false>);
+        auto pickd = [&](auto sc) -> KernD {
+            constexpr bool SC = decltype(sc)::value;
+            if (s.neg_lo_all)
+                return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, true, SC> : &k_gp_dense<T, false, 256, true, SC>)
+                                        : (s.degenerate ? &k_gp_dense<T, true, 512, true, SC> : &k_gp_dense<T, false, 512, true, SC>);
+            return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false, SC> : &k_gp_dense<T, false, 256, false, SC>)
+                                    : (s.degenerate ? &k_gp_dense<T, true, 512, false, SC> : &k_gp_dense<T, false, 512, false, SC>);
+        };
+        const KernD kern = s.scaled ? pickd(std::true_type{}) : pickd(std::false_type{});
         s.kern[0] = reinterpret_cast<const void*>(kern);
-        s.hip_kernel = "k_gp_dense<" + tn + "," + dg + "," + std::to_string(s.threads) + "," + (s.neg_lo_all ? "true" : "false") + ">";
+        s.hip_kernel = "k_gp_dense<" + tn + "," + dg + "," + std::to_string(s.threads) + "," + (s.neg_lo_all ? "true" : "false") + (s.scaled ? ",true>" : ">");
         if (int st = allow_lds(s.kern[0], s.lds)) return st;
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
@@ -714,7 +734,8 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         s.d_domain = prog->d_domain;
         // kernel choice, LDS budget, persistent grid: fixed here, and a program no kernel can run is refused whole
         const Layout la = layout_of(s.a), lb = layout_of(s.b);
-        if (int st = plan.dtype == GAAST_F32 ? prepare_step<float>(s, la, lb, plan.n) : prepare_step<double>(s, la, lb, plan.n))
+        const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;   // parity-pure products run in Cl(n - 1)
+        if (int st = plan.dtype == GAAST_F32 ? prepare_step<float>(s, la, lb, step_n) : prepare_step<double>(s, la, lb, step_n))
             return st;
         if (s.a.idx >= 0 && s.a.kind == BufKind::INPUT) plan.slot_used[size_t(s.a.idx)] = 1;
         if (s.b.idx >= 0 && s.b.kind == BufKind::INPUT) plan.slot_used[size_t(s.b.idx)] = 1;
@@ -1008,8 +1029,9 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         Bound a{nullptr, 0}, b{nullptr, 0};
         if (s.a.idx >= 0) a = resolve(s.a, &la);
         if (s.b.idx >= 0) b = resolve(s.b, &lb);
-        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, plan.n)
-                                               : run_step<double>(s, res, a, b, la, lb, count, plan.n);
+        const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;
+        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, step_n)
+                                               : run_step<double>(s, res, a, b, la, lb, count, step_n);
         if (st != GAAST_OK) return st;
     }
     return GAAST_OK;

@@ -107,8 +107,10 @@ static uint32_t mfma16q_b_pos(uint32_t m) {
 }
 
 static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
-                                             const char* expect_step) {
-    gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n);
+                                             const char* expect_step, uint64_t lmask = 0, uint64_t rmask = 0) {
+    if (!lmask) lmask = full_mask(n);
+    if (!rmask) rmask = full_mask(n);
+    gaast_expr_t a = gaast_expr_input(0, lmask, n), b = gaast_expr_input(1, rmask, n);
     gaast_expr_t e = gaast_expr_product(a, b, GAAST_PROD_GEOMETRIC);
     gaast_spec_t spec = gaast_expr_specialize(e, n, metric, uint64_t(1) << 22);
     CHECK(spec != nullptr);
@@ -127,14 +129,16 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
         return;
     }
     CHECK(st->name.find(expect_step) != std::string::npos);
-    const uint32_t N = 1u << n;
+    // the kernel's algebra: the program's, or Cl(n - 1) for parity-pure operands (st->dense_n)
+    const int n2 = st->dense_n ? st->dense_n : n;
+    const uint32_t N = 1u << n2, NROW = 1u << n;
     const int L = st->use_mfma ? 5 : 4;
     // operands: a fixed pseudo-random row each (exact small integers: every sum below is exact)
-    std::vector<double> lrow(N), rrow(N);
+    std::vector<double> lrow(NROW), rrow(NROW);
     uint64_t x = 88172645463325252ULL;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return double(int(x % 17) - 8); };
-    for (uint32_t i = 0; i < N; ++i) lrow[i] = rnd();
-    for (uint32_t i = 0; i < N; ++i) rrow[i] = rnd();
+    for (uint32_t i = 0; i < NROW; ++i) lrow[i] = rnd();
+    for (uint32_t i = 0; i < NROW; ++i) rrow[i] = rnd();
     // images in permuted-blade order
     std::vector<uint32_t> inv_vec(N), inv_b(N);
     for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
@@ -169,7 +173,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     for (uint32_t pa = 0; pa < N; ++pa)
         for (uint32_t pb = 0; pb < N; ++pb) {
             int par = 0;
-            for (int p = 1; p < n; ++p)
+            for (int p = 1; p < n2; ++p)
                 if ((pa >> p) & 1u) par ^= __builtin_popcount(pb & ((1u << p) - 1u)) & 1;
             const uint32_t sh = pa & pb;
             par ^= __builtin_popcount((sh & lomask) & st->neg_lo) & 1;
@@ -177,29 +181,33 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
             if ((sh >> L) & st->zero_hi) continue;
             Cp[pa ^ pb] += (par ? -1.0 : 1.0) * A[pa] * B[pb];
         }
-    std::vector<double> got(N, 0.0);
+    std::vector<double> got(NROW, 0.0);
     for (uint32_t m = 0; m < N; ++m) {
         const int32_t w = st->i32_a[m];
         if (w < 0) continue;
         got[size_t(w & 0x3fffffff)] = ((w & 0x40000000) ? -Cp[m] : Cp[m]) * (st->scaled ? st->coeff_c[m] : 1.0);
     }
-    // the reference's list (specialize.rs:162-183), on graded rows
-    std::vector<double> want(N, 0.0);
-    std::vector<uint64_t> goff(size_t(n) + 2, 0);
-    for (int k = 0; k <= n; ++k) goff[size_t(k) + 1] = goff[size_t(k)] + gaast_n_choose_k(uint64_t(n), uint64_t(k));
+    // the reference's list (specialize.rs:162-183), on graded rows (each buffer laid out by its own grade set)
+    std::vector<double> want(NROW, 0.0);
     const int root = gaast_spec_root(spec);
     gaast_spec_node_info info;
     CHECK(gaast_spec_node(spec, root, &info) == 0);
+    auto offsets = [&](uint64_t mask) {
+        std::vector<uint64_t> off(size_t(n) + 2, 0);
+        for (int k = 0; k <= n; ++k) off[size_t(k) + 1] = off[size_t(k)] + (((mask >> k) & 1ULL) ? gaast_n_choose_k(uint64_t(n), uint64_t(k)) : 0);
+        return off;
+    };
+    const std::vector<uint64_t> loff = offsets(lmask), roff = offsets(rmask), ooff = offsets(info.minimal_grade_mask);
     const gaast_comp_mul* muls = gaast_spec_comp_muls(spec, root);
-    CHECK(muls != nullptr && info.n_comp_muls == (uint64_t(1) << (2 * n)));
+    CHECK(muls != nullptr && (lmask != full_mask(n) || rmask != full_mask(n) || info.n_comp_muls == (uint64_t(1) << (2 * n))));
     if (muls)
         for (uint64_t i = 0; i < info.n_comp_muls; ++i) {
             const gaast_comp_mul& m = muls[i];
-            want[goff[m.result_grade] + m.result_index] += lrow[goff[m.left_grade] + m.left_index] * rrow[goff[m.right_grade] + m.right_index] * m.coeff;
+            want[ooff[m.result_grade] + m.result_index] += lrow[loff[m.left_grade] + m.left_index] * rrow[roff[m.right_grade] + m.right_index] * m.coeff;
         }
     size_t bad = 0;
-    for (uint32_t i = 0; i < N; ++i) bad += got[i] != want[i];
-    if (bad) std::printf("%s: %zu of %u components differ\n", what, bad, N);
+    for (uint32_t i = 0; i < NROW; ++i) bad += got[i] != want[i];
+    if (bad) std::printf("%s: %zu of %u components differ\n", what, bad, NROW);
     CHECK(bad == 0);
     gaast_spec_free(spec);
     std::printf("ok  %s (%s)\n", what, st->name.c_str());
@@ -319,6 +327,28 @@ int main() {
         dense_tables_agree_with_the_list(7, gen7, GAAST_F32, 0, "vector tables n=7 general metric", "rescaled basis");
         dense_tables_agree_with_the_list(10, gen10, GAAST_F32, 0, "mfma32p tables n=10 general metric", "rescaled basis");
         dense_tables_agree_with_the_list(10, gen10, GAAST_F64, 0, "mfma16x4 f64 tables n=10 general metric", "rescaled basis");
+        // parity-pure operands: one product in the even subalgebra Cl(n - 1) (plan.cpp: parity_reduced_frame), all four
+        // parity cases, Euclidean / mixed / degenerate / general metrics, the pivot not always the last vector
+        const uint64_t EV = 0x5555555555555555ULL, OD = 0xAAAAAAAAAAAAAAAAULL;
+        const double mix9[9] = {1, -1, 1, 1, -1, 1, -1, 1, -1};
+        const double deg9[9] = {1, 0, -1, 1, 1, 1, -1, 1, 0};          // the last vector is null: the pivot is e_8
+        const double gen9[9] = {4, 1, -0.25, 1, 16, 1, -1, 0.25, -4};
+        struct { uint64_t l, r; const char* tag; } cases[4] = {{EV, EV, "even x even"}, {EV, OD, "even x odd"}, {OD, EV, "odd x even"}, {OD, OD, "odd x odd"}};
+        for (auto& pc : cases) {
+            char what[96];
+            std::snprintf(what, sizeof what, "parity-pure n=9 euclid f64 %s", pc.tag);
+            dense_tables_agree_with_the_list(9, euclid, GAAST_F64, 0, what, pc.tag, pc.l & full_mask(9), pc.r & full_mask(9));
+            std::snprintf(what, sizeof what, "parity-pure n=9 mixed f32 %s", pc.tag);
+            dense_tables_agree_with_the_list(9, mix9, GAAST_F32, 0, what, pc.tag, pc.l & full_mask(9), pc.r & full_mask(9));
+            std::snprintf(what, sizeof what, "parity-pure n=9 degenerate f64 %s", pc.tag);
+            dense_tables_agree_with_the_list(9, deg9, GAAST_F64, 0, what, pc.tag, pc.l & full_mask(9), pc.r & full_mask(9));
+            std::snprintf(what, sizeof what, "parity-pure n=9 general metric f64 %s", pc.tag);
+            dense_tables_agree_with_the_list(9, gen9, GAAST_F64, 0, what, pc.tag, pc.l & full_mask(9), pc.r & full_mask(9));
+            std::snprintf(what, sizeof what, "parity-pure n=8 vector kernel f32 %s", pc.tag);
+            dense_tables_agree_with_the_list(8, mix9, GAAST_F32, 0, what, pc.tag, pc.l & full_mask(8), pc.r & full_mask(8));
+        }
+        const double mix11[11] = {1, -1, 1, 1, 0, 1, -1, 1, -1, 1, 1};
+        dense_tables_agree_with_the_list(11, mix11, GAAST_F32, 0, "parity-pure n=11 -> mfma32p<10> odd x even", "odd x even", OD & full_mask(11), EV & full_mask(11));
     }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {

@@ -15,21 +15,24 @@ from helpers import abs_terms_bound, bits_to_row, full_grades, hip_eval_batch, o
 pytestmark = pytest.mark.gpu
 
 
-def _gp(n, left_grades=None):
+def _gp(n, left_grades=None, right_grades=None):
     lg = full_grades(n) if left_grades is None else left_grades
+    rg = full_grades(n) if right_grades is None else right_grades
 
     def build(B):
-        return B.input(0, lg, n) * B.input(1, full_grades(n), n)
+        return B.input(0, lg, n) * B.input(1, rg, n)
     return build, lg
 
 
-def _check(n, metric, left_grades, variants, batch, seed, out_grades=None, eps_factor=4, exact_order_too=False):
+def _check(n, metric, left_grades, variants, batch, seed, out_grades=None, eps_factor=4, exact_order_too=False, right_grades=None,
+           label_has=None):
     """variants: [(dtype, flags, expected launch-name prefix, HIP kernel)]; one oracle evaluation serves them all.  The launch
     label names the HIP kernel instantiation prepare_step picked ("<what> :: <kernel<...>>", the name rocprofv3 reports):
     the test asserts it, so a docstring cannot go stale about which kernel it covers."""
-    build, lg = _gp(n, left_grades)
+    build, lg = _gp(n, left_grades, right_grades)
+    rg = full_grades(n) if right_grades is None else right_grades
     rng = np.random.default_rng(seed)
-    rows = {0: rows_of(n, lg, batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    rows = {0: rows_of(n, lg, batch, rng, np.float32), 1: rows_of(n, rg, batch, rng, np.float32)}
     rows64 = {s: r.astype(np.float64) for s, r in rows.items()}     # the same values, exactly representable in both types
     alg = metric if any(m != 1.0 for m in metric) else n
     want, wmask = oracle_eval_batch(build, alg, rows64, batch)
@@ -38,10 +41,12 @@ def _check(n, metric, left_grades, variants, batch, seed, out_grades=None, eps_f
         got, mask, spec = hip_eval_batch(build, alg, rows if dtype == ga.F32 else rows64, batch, dtype=dtype, flags=flags)
         assert mask == wmask
         assert any(l.startswith(prefix) and l.split(" :: ")[-1].startswith(kernel) for l in spec.launches()), (prefix, kernel, spec.launches())
+        if label_has:
+            assert any(label_has in l for l in spec.launches()), (label_has, spec.launches())
         eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
         general = any(m not in (1.0, -1.0, 0.0) for m in metric)
         for i in range(batch):
-            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, full_grades(n), rows64[1][i]), metric if general else None)
+            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, rg, rows64[1][i]), metric if general else None)
             bound = eps_factor * eps * bits_to_row(n, og, S) + 1e-300
             err = np.abs(got[i].astype(np.float64) - want[i])
             assert np.all(err <= bound), (prefix, dtype, i, float((err / bound).max()))
@@ -277,10 +282,10 @@ def test_general_diagonal_metric_at_n12_and_partial_operands():
     """a 12-dimensional general metric on the headline kernel (k_gp_mfma32p) and on k_gp_mfma16x4<double>, and at n = 10 with a
     left operand that misses grades (the scale table follows the map, not the blade index)"""
     metric = [1.0, 2.0, -0.5, 1.0, 3.0, 1.0, -1.0, 0.25, 1.0, 1.0, -4.0, 1.5]
-    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,12>"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,12,")],
+    _check(12, metric, None, [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<false,12,true>"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,12,")],
            batch=1, seed=312, eps_factor=8)
     metric10 = [2.0, 1.0, -0.5, 1.0, 0.0, 1.0, -1.0, 0.25, 3.0, 1.0]
-    _check(10, metric10, [0, 1, 2, 3, 4, 5, 6, 7], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<true,10>"),
+    _check(10, metric10, [0, 1, 2, 3, 4, 5, 6, 7], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma32p<true,10,true>"),
                                                      (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,true,10,")], batch=2, seed=310, eps_factor=8)
 
 
@@ -295,3 +300,33 @@ def test_a_metric_too_wild_to_rescale_stays_on_the_list_kernels():
     got, _, spec = hip_eval_batch(build, metric, rows, 2)
     assert not any("product_dense" in l for l in spec.launches()), spec.launches()
     assert np.array_equal(got, want)
+
+
+EVEN = lambda n: [k for k in range(n + 1) if k % 2 == 0]
+ODD = lambda n: [k for k in range(n + 1) if k % 2 == 1]
+
+
+@pytest.mark.parametrize("lpar,rpar", [("even", "even"), ("even", "odd"), ("odd", "even"), ("odd", "odd")])
+@pytest.mark.parametrize("n,metric", [(9, [1.0] * 9), (10, [1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 0.0, 1.0, -1.0, 1.0]), (12, [1.0] * 12)])
+def test_parity_pure_operands_run_in_the_even_subalgebra(n, metric, lpar, rpar):
+    """The reference only multiplies the entries it needs (specialize.rs:162-183): even x even (rotor composition, the second
+    product of every sandwich) is a quarter of the 4^n table.  Round 2's dense kernels always did 4^n multiply-adds; now a
+    product of parity-pure operands is ONE product in Cl(n - 1) (plan.cpp: parity_reduced_frame) -- 4^(n-1) multiply-adds --
+    for all four parity combinations, against the oracle within 4 eps sum|terms| in both value types."""
+    if n == 12 and (lpar, rpar) not in (("even", "even"), ("odd", "even")):
+        pytest.skip("n = 12: two of the four cases (each builds a 4.2 M-entry oracle table)")
+    lg, rg = (EVEN if lpar == "even" else ODD)(n), (EVEN if rpar == "even" else ODD)(n)
+    dg = "true" if 0.0 in metric else "false"
+    f32_kernel = {8: f"k_gp_mfma16x4<float,{dg},8,", 9: f"k_gp_mfma16x4<float,{dg},9,", 11: f"k_gp_mfma32p<{dg},11>"}[n - 1]
+    variants = [(ga.F32, 0, "product_dense_mfma[", f32_kernel), (ga.F64, 0, "product_dense_mfma[", f"k_gp_mfma16x4<double,{dg},{n - 1},")]
+    _check(n, metric, lg, variants, batch=3 if n < 12 else 1, seed=500 + n, right_grades=rg, label_has=f"{lpar} x {rpar} in Cl({n - 1})")
+
+
+def test_parity_pure_with_a_general_metric_and_partial_grades():
+    """even x even with a general diagonal metric (the reduction's own factors are powers of 1 / g_p: they ride in the scale
+    tables), and a rotor-like left operand holding only grades 0, 2, 4 of the even grades (general staging, zeros elsewhere)"""
+    metric = [2.0, 1.0, -0.5, 1.0, 3.0, 1.0, -1.0, 0.25, 1.5]
+    _check(9, metric, EVEN(9), [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma16x4<float,false,8,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,8,")],
+           batch=3, seed=520, right_grades=ODD(9), eps_factor=8, exact_order_too=True, label_has="even x odd in Cl(8)")
+    _check(10, [1.0] * 10, [0, 2, 4, 6], [(ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,9,")], batch=2, seed=521,
+           right_grades=EVEN(10), label_has="even x even in Cl(9)")

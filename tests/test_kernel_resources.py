@@ -1,0 +1,75 @@
+"""Register budgets of the hot kernels, read from the gfx950 code object inside libgaast_hip.so (no GPU needed).
+
+Occupancy decides these kernels: k_gp_mfma32p<false, 12> (the headline, BASELINE configs[2]) must fit TWO waves per SIMD
+(vgpr + agpr <= 256 of the 512 registers per lane); round 3 once lost 18 % of the headline to 13 extra registers from an
+unrelated code path (267 -> one wave per SIMD).  No kernel may spill."""
+import re
+import struct
+import subprocess
+
+import pytest
+
+from gaast_amd import _lib
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+CXXFILT = "c++filt"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    data = open(_lib.LIB_PATH, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0, "no offload bundle in the library"
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off, co = i + 32, None
+    for _ in range(n):
+        o, sz, tl = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        triple = data[off:off + tl].decode()
+        off += tl
+        if "gfx950" in triple:
+            co = data[i + o:i + o + sz]
+    assert co, "no gfx950 code object"
+    path = tmp_path_factory.mktemp("co") / "gaast.co"
+    path.write_bytes(co)
+    notes = subprocess.run([READELF, "--notes", str(path)], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for block in notes.split("  - .agpr_count:")[1:]:
+        agpr = int(block.split()[0])
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1))
+        sspill = int(re.search(r"\.sgpr_spill_count:\s+(\d+)", block).group(1))
+        lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", block).group(1))
+        out[name] = dict(vgpr=vgpr, agpr=agpr, spill=spill, sgpr_spill=sspill, lds=lds)
+    names = subprocess.run([CXXFILT], input="\n".join(out), capture_output=True, text=True, check=True).stdout.split("\n")
+    return {d.replace("void gaast::", "").split("(")[0]: v for d, v in zip(names, out.values())}
+
+
+def _find(kernels, prefix):
+    hits = {k: v for k, v in kernels.items() if k.startswith(prefix)}
+    assert hits, (prefix, sorted(kernels)[:20])
+    return hits
+
+
+def test_spills_stay_out_of_the_hot_kernels(kernels):
+    """a handful of registers spill in the 1,024-thread n = 12 f64 instantiations for degenerate metrics / a rescaled basis
+    (128 registers per thread); nothing else spills, and never more than a few registers"""
+    bad = {k: v["spill"] for k, v in kernels.items() if v["spill"]}
+    assert all(k.startswith("k_gp_mfma16x4<double, ") and ", 12, " in k and (k.startswith("k_gp_mfma16x4<double, true") or k.endswith(", true>"))
+               for k in bad), bad
+    assert all(v <= 8 for v in bad.values()), bad
+
+
+@pytest.mark.parametrize("prefix,waves", [
+    ("k_gp_mfma32p<false, 12, false>", 2),                 # the headline: two waves per SIMD
+    ("k_gp_mfma32p<false, 10, false>", 2), ("k_gp_mfma32p<false, 11, false>", 2),
+    ("k_gp_mfma16x4<float, false, 8, 2, false>", 6),       # BASELINE configs[1]
+    ("k_gp_mfma16x4<double, false, 12, 2, false>", 4),     # r12d: 16 waves per item, one item per CU
+    ("k_gp_spinor12s<5, true>", 2),
+])
+def test_hot_kernels_keep_their_occupancy(kernels, prefix, waves):
+    for name, k in _find(kernels, prefix).items():
+        regs = -(-k["vgpr"] // 8) * 8          # .vgpr_count is the unified total (arch + accumulation registers); granule: 8
+        assert k["spill"] == 0, (name, k)
+        assert regs * waves <= 512, (name, k, f"{regs} registers: fewer than {waves} waves per SIMD")
