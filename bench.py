@@ -120,6 +120,21 @@ def workload_spec(name):
                     default_batch=1 << 22,
                     label="R^{4,1} rotor sandwich R X ~R with one shared rotor, f64")
     import re
+    m = re.fullmatch(r"sand(\d+)(g1)?(x)?", name)   # sand8 / sand9 / sand10: BASELINE configs[4]'s pipeline where it no longer fits one fused launch
+    if m:
+        # the rotor sandwich R X ~R (R even, X grade 1; f64) at n = 8 (R^8), 9 (R^{6,3}), 10 (R^10): 80 / 256-entry tables become
+        # n 2^(n-1) + 4^(n-1) entries; sandNg1 projects on grade 1, sandNx keeps the reference's summation order
+        n = int(m.group(1))
+        metric = [1.0] * 6 + [-1.0] * 3 if n == 9 else [1.0] * n
+        even = [k for k in range(n + 1) if k % 2 == 0]
+        half = 1 << (n - 1)
+        g1 = bool(m.group(2))
+        return dict(n=n, metric=metric, dtype=ga.F64, dtname="f64", inputs=[even, [1]],
+                    build=(lambda r, x: (r * x * r.rev()).g(1)) if g1 else (lambda r, x: r * x * r.rev()),
+                    entries=n * half + (n * half if g1 else half * half), default_batch=max(1024, min(1 << 22, (1 << 30) // (half * 8))),
+                    flags=ga.FLAG_EXACT_ORDER if m.group(3) else 0,
+                    label=f"rotor sandwich {'(R X ~R).g(1)' if g1 else 'R X ~R'} in {'R^{6,3}' if n == 9 else 'R^%d' % n}, R even ({half} components), X grade 1, f64"
+                          + (", reference summation order" if m.group(3) else ""))
     m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x|ee|eo|oe|oo)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order), gp12f32ee (even x even)
     if m:
         n, dt, var = int(m.group(1)), m.group(2), m.group(3)

@@ -24,6 +24,7 @@ OP_NAMES = ["GradedObj", "Addition", "Product", "Negation", "Exponential", "Loga
 PROD_EXPLICIT, PROD_GEOMETRIC, PROD_OUTER, PROD_INNER, PROD_LCONTRACT, PROD_RCONTRACT = -1, 0, 1, 2, 3, 4
 FLAG_DEBUG_OVERFLOW, FLAG_NO_FUSION, FLAG_EXACT_ORDER, FLAG_NO_MFMA, FLAG_NO_JIT, FLAG_SPINOR_GEMM = 1, 2, 4, 8, 16, 32
 FLAG_DEBUG_JIT_FAILS, FLAG_DEBUG_KEEP_JIT_SOURCE, FLAG_EXP_LOG, FLAG_NO_COALESCE, FLAG_DEBUG_LDS_12K = 0x40, 0x80, 0x100, 0x200, 0x400
+FLAG_DEBUG_NO_CHAIN = 0x800
 COMM_ID_BYTES = 128
 
 

@@ -56,6 +56,20 @@ struct DenseArgs {
     const T* left_scale;
     const T* right_scale;
     const T* out_scale;
+    // chained product (plan.cpp: chain_sparse_into_dense): the LEFT operand is the result of a short comp-mul list over two
+    // other rows; it is evaluated in LDS while staging (stage_from_list), `left` is unused.  NULL otherwise.
+    const T* pre_left;
+    const T* pre_right;
+    int64_t pre_left_stride, pre_right_stride;
+    int pre_left_len, pre_right_len, pre_canon_left, pre_canon_right;
+    const uint32_t* pre_row_start;   // pre_rows + 1
+    const uint32_t* pre_entries;     // left offset | right offset << 16
+    const T* pre_coeff;
+    const uint32_t* pre_row_map;     // per row: image position << 16 | negate << 31
+    const T* pre_row_scale;          // per row (rescaled basis) or NULL
+    int pre_rows;
+    int pre_width;                   // > 0: rows of one length, +-1 coefficients: pre_entries is [term][row], sign in bit 31
+    int pre_scratch;                 // element offset of the list's operand rows in the kernel's LDS
     int left_signs;             // some left_map word has its negate bit set (folded sign arms, permuted basis)
     int out_signs;              // some out_map word has its sign bit set (permuted basis)
     int64_t batch;
@@ -70,6 +84,30 @@ __device__ __forceinline__ int dense_lds_pos(int m) {
 }
 
 
+// e = it * cnt + j with 0 <= j < cnt, for e < 2^24: a float reciprocal and one correction step instead of the ~30
+// instructions of an integer division by a run-time value (every vector instruction of a resident wave costs its SIMD ~4.8
+// cycles of matrix-pipe time: the general staging spent most of its time dividing).  nitems == 1 (known at compile time in the
+// one-item-per-workgroup kernels): nothing to divide.
+__device__ __forceinline__ void split_index(int e, int cnt, float inv_cnt, int nitems, int& it, int& j) {
+    if (nitems == 1) {
+        it = 0;
+        j = e;
+        return;
+    }
+    int q = int(float(e) * inv_cnt);
+    int r = e - q * cnt;
+    if (r < 0) {
+        --q;
+        r += cnt;
+    }
+    if (r >= cnt) {
+        ++q;
+        r -= cnt;
+    }
+    it = q;
+    j = r;
+}
+
 // Scatter the operand rows of `nitems` items into their LDS images.  A map word is
 //   row offset [15:0] | position in the LDS image [30:16] | negate [31]
 // (the position is computed on the host for the kernel that consumes the image).  Loads of a
@@ -80,9 +118,11 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
                                                int count, int contig4, int canon, T* __restrict__ images,
                                                int image_stride, int nitems, int tid, const T* __restrict__ scale = nullptr) {
     constexpr int U = 4;
+    const float inv_count = 1.0f / float(count > 0 ? count : 1);
     if (contig4) {
         const int total4 = (nitems * count) >> 2;  // count % 4 == 0
         const int count4 = count >> 2;
+        const float inv_count4 = 1.0f / float(count4 > 0 ? count4 : 1);
         for (int e0 = tid; e0 < total4; e0 += THREADS * U) {
             uint4 m[U];
             T v[U][4];
@@ -90,7 +130,8 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
             for (int k = 0; k < U; ++k) {
                 const int e = e0 + k * THREADS;
                 if (e < total4) {
-                    const int it = e / count4, j4 = e - it * count4;
+                    int it, j4;
+                    split_index(e, count4, inv_count4, nitems, it, j4);
                     m[k] = reinterpret_cast<const uint4*>(map)[j4];
                     const T* rp = src + int64_t(it) * stride + (j4 << 2);
                     if (sizeof(T) == 4) {
@@ -106,14 +147,15 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
             for (int k = 0; k < U; ++k) {
                 const int e = e0 + k * THREADS;
                 if (e < total4) {
-                    const int it = e / count4;
+                    int it, j4;
+                    split_index(e, count4, inv_count4, nitems, it, j4);
                     T* img = images + it * image_stride;
                     const uint32_t mm[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         T x = v[k][c];
                         if (canon) x = T(0) + x;  // the reference's zero-init + add_grades_from copy: 0.0 + x
-                        if (scale) x = x * scale[((e - (e / count4) * count4) << 2) + c];   // rescaled basis: w_S A_S
+                        if (scale) x = x * scale[(j4 << 2) + c];   // rescaled basis: w_S A_S
                         if (mm[c] >> 31) x = -x;  // a folded Negation / Reverse / GradeInvolution of this grade
                         img[(mm[c] >> 16) & 0x7fffu] = x;
                     }
@@ -126,15 +168,17 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
     for (int e0 = tid; e0 < total; e0 += THREADS * U) {
         uint32_t m[U];
         T v[U];
+        int its[U], js[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const int e = e0 + k * THREADS;
-            m[k] = e < total ? map[e % count] : 0u;
+            split_index(e < total ? e : 0, count, inv_count, nitems, its[k], js[k]);
+            m[k] = e < total ? map[js[k]] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const int e = e0 + k * THREADS;
-            v[k] = e < total ? src[int64_t(e / count) * stride + (m[k] & 0xffffu)] : T(0);
+            v[k] = e < total ? src[int64_t(its[k]) * stride + (m[k] & 0xffffu)] : T(0);
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -142,9 +186,100 @@ __device__ __forceinline__ void stage_operands(const T* __restrict__ src, int64_
             if (e < total) {
                 T x = v[k];
                 if (canon) x = T(0) + x;
-                if (scale) x = x * scale[e % count];
+                if (scale) x = x * scale[js[k]];
                 if (m[k] >> 31) x = -x;
-                images[(e / count) * image_stride + ((m[k] >> 16) & 0x7fffu)] = x;
+                images[its[k] * image_stride + ((m[k] >> 16) & 0x7fffu)] = x;
+            }
+        }
+    }
+}
+
+// The left operand of a CHAINED product: rows of a comp-mul list over two other operand rows, evaluated here, in LDS, in the
+// reference's order with its roundings (eval.rs:82: `res += (left * right) * coeff`, no contraction) -- bit for bit what
+// k_product_csr / k_product_ell would have written to HBM.  scratch: nitems x (pre_left_len + pre_right_len) elements.  Ends
+// with the operand image written; the caller's barrier follows.
+//   pre_width > 0: every row has pre_width entries with coefficients +-1 (sparse products of non-degenerate algebras: R X has n
+//   per row): the list is stored [term][row] with the sign in bit 31, so that a wave's rows read consecutive words, no
+//   coefficient is loaded ((l r) (-1.0) == -(l r) exactly), and -- up to 16 terms -- a thread keeps its row's entries in
+//   registers for all the items it serves.  Otherwise: CSR with general coefficients.
+template <typename T>
+__device__ __forceinline__ T list_flip(T v, uint32_t sign31);
+template <>
+__device__ __forceinline__ float list_flip<float>(float v, uint32_t sign31) { return __uint_as_float(__float_as_uint(v) ^ sign31); }
+template <>
+__device__ __forceinline__ double list_flip<double>(double v, uint32_t sign31) {
+    return __hiloint2double(__double2hiint(v) ^ int(sign31), __double2loint(v));
+}
+
+template <typename T, int THREADS>
+__device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t item0, int nitems, T* __restrict__ images,
+                                                int image_stride, T* __restrict__ scratch, int tid) {
+    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl;
+    const T zero = T(0);
+    const float inv_per = 1.0f / float(per > 0 ? per : 1);
+    for (int e = tid; e < nitems * per; e += THREADS) {
+        int it, c;
+        split_index(e, per, inv_per, nitems, it, c);
+        T v;
+        if (c < ll) {
+            v = p.pre_left[(item0 + it) * p.pre_left_stride + c];
+            if (p.pre_canon_left) v = zero + v;
+        } else {
+            v = p.pre_right[(item0 + it) * p.pre_right_stride + (c - ll)];
+            if (p.pre_canon_right) v = zero + v;
+        }
+        scratch[e] = v;
+    }
+    if (THREADS > 64) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // a single wave: its own writes, in order
+    const int R = p.pre_rows;
+    // rows are dealt to threads; when there are more threads than rows, THREADS / R groups of threads serve different items
+    const int G = THREADS >= R ? THREADS / R : 1;
+    const int g = THREADS >= R ? tid / R : 0;
+    const int row_step = THREADS >= R ? R : THREADS;
+    if (g >= G) return;
+    for (int row = THREADS >= R ? tid - g * R : tid; row < R; row += row_step) {
+        const uint32_t w = p.pre_row_map[row];
+        const uint32_t pos = (w >> 16) & 0x7fffu, neg = w & 0x80000000u;
+        const T sc = p.pre_row_scale ? p.pre_row_scale[row] : T(1);
+        if (p.pre_width > 0 && p.pre_width <= 16) {
+            uint32_t ev[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ev[k] = k < p.pre_width ? p.pre_entries[k * R + row] : 0u;
+            for (int it = g; it < nitems; it += G) {
+                const T* l = scratch + it * per;
+                const T* r = l + ll;
+                T acc = zero;                                      // the fresh cache buffer of eval.rs:21-33
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < p.pre_width) acc = acc + list_flip<T>(l[ev[k] & 0x7fffu] * r[(ev[k] >> 16) & 0x7fffu], ev[k] & 0x80000000u);   // eval.rs:82
+                if (p.pre_row_scale) acc = acc * sc;
+                images[it * image_stride + pos] = list_flip<T>(acc, neg);
+            }
+        } else if (p.pre_width > 0) {
+            for (int it = g; it < nitems; it += G) {
+                const T* l = scratch + it * per;
+                const T* r = l + ll;
+                T acc = zero;
+                for (int k = 0; k < p.pre_width; ++k) {
+                    const uint32_t e = p.pre_entries[k * R + row];
+                    acc = acc + list_flip<T>(l[e & 0x7fffu] * r[(e >> 16) & 0x7fffu], e & 0x80000000u);
+                }
+                if (p.pre_row_scale) acc = acc * sc;
+                images[it * image_stride + pos] = list_flip<T>(acc, neg);
+            }
+        } else {
+            const uint32_t e0 = p.pre_row_start[row], e1 = p.pre_row_start[row + 1];
+            for (int it = g; it < nitems; it += G) {
+                const T* l = scratch + it * per;
+                const T* r = l + ll;
+                T acc = zero;
+                for (uint32_t k = e0; k < e1; ++k) {
+                    const uint32_t lr = p.pre_entries[k];
+                    acc = acc + (l[lr & 0xffffu] * r[lr >> 16]) * p.pre_coeff[k];   // eval.rs:82
+                }
+                if (p.pre_row_scale) acc = acc * sc;
+                images[it * image_stride + pos] = list_flip<T>(acc, neg);
             }
         }
     }
@@ -326,8 +461,11 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
                 for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
                 __syncthreads();
             }
-            stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem, item_stride, nitems, tid, left_scale);
+            if (p.pre_entries)
+                stage_from_list<T, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
+            else
+                stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                           p.canon_left, smem, item_stride, nitems, tid, left_scale);
             stage_operands<T, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
                                        p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, right_scale);
         }
@@ -433,7 +571,10 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         __syncthreads();
     }
     {
-        stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+        if (p.pre_entries)
+            stage_from_list<float, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
+        else
+            stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
                                        p.canon_left, smem, item_stride, nitems, tid, left_scale);
         stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
                                        p.right_contig, p.canon_right, smem + N, item_stride, nitems, tid, right_scale);
@@ -714,7 +855,10 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                 for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
                 lds_barrier<THREADS>();
             }
-            stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+            if (p.pre_entries)
+                stage_from_list<float, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
+            else
+                stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
                                            p.canon_left, smem, item_stride, nitems, tid, left_scale);
             stage_operands<float, THREADS>(p.right + item0 * p.right_stride, p.right_stride, p.right_map, p.right_count,
                                            p.right_contig, p.canon_right, smem + 2 * N, item_stride, nitems, tid, right_scale);
@@ -1088,8 +1232,11 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                 for (int e = tid; e < 4 * N + PAD_A; e += THREADS) smem[e] = T(0);
                 lds_barrier<THREADS>();
             }
-            stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
-                                       p.canon_left, smem + A_EL, item_stride, 1, tid, left_scale);
+            if (p.pre_entries)
+                stage_from_list<T, THREADS>(p, item, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid);
+            else
+                stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                           p.canon_left, smem + A_EL, item_stride, 1, tid, left_scale);
             stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
                                        p.right_contig, p.canon_right, smem + B_EL, item_stride, 1, tid, right_scale);
             lds_barrier<THREADS>();

@@ -1496,6 +1496,122 @@ static void uniform_csr_to_ell(Plan& plan) {
     }
 }
 
+// A sparse product whose result is read ONLY as the left operand of a dense product (R X in R X ~R, eval.rs:61-86 with its
+// cached operand) is evaluated inside the dense kernel, in LDS, while that kernel stages its operands: one launch instead of
+// two, and the intermediate row never goes through HBM (BASELINE configs[4] at the dimensions where the whole program no
+// longer fits a fused small-program kernel).  The list keeps the reference's order and roundings, so the dense kernel sees
+// the very bits the separate launch would have written.  Off with GAAST_FLAG_DEBUG_NO_CHAIN (A/B, tests).
+static void chain_sparse_into_dense(Plan& plan) {
+    if (plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_DEBUG_NO_CHAIN)) return;
+    plan.node_dead.assign(plan.node_buffers.size(), 0);
+    const size_t elem = plan.dtype == GAAST_F32 ? 4 : 8;
+    auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
+    for (size_t j = 0; j < plan.steps.size(); ++j) {
+        Step& dn = plan.steps[j];
+        if (dn.kind != Step::PRODUCT_DENSE || dn.use_spinor || dn.chained || dn.a.kind != BufKind::NODE) continue;
+        const BufRef buf = dn.a;
+        // exactly one writer (a list product that starts the buffer: beta = 0), no other reader, nothing else touches it
+        int writer = -1;
+        bool ok = !same(dn.b, buf);
+        for (size_t i = 0; i < plan.steps.size() && ok; ++i) {
+            const Step& t = plan.steps[i];
+            if (i == j) continue;
+            if (t.kind == Step::FUSED) ok = false;
+            if (same(t.res, buf)) {
+                if (writer >= 0 || t.kind != Step::PRODUCT_CSR || t.beta != 0 || i > j) ok = false;
+                writer = int(i);
+            }
+            if ((t.a.idx >= 0 && same(t.a, buf)) || (t.b.idx >= 0 && same(t.b, buf))) ok = false;
+            if (t.chained && (same(t.pre_a, buf) || same(t.pre_b, buf))) ok = false;
+        }
+        if (!ok || writer < 0) continue;
+        Step& w = plan.steps[size_t(writer)];
+        // the list's operands must still hold at the dense launch: inputs always do; a cache buffer does unless a later step
+        // writes it (cache buffers are written by the steps that fill them, all before their first reader)
+        for (size_t i = size_t(writer) + 1; i < j && ok; ++i)
+            if (same(plan.steps[i].res, w.a) || same(plan.steps[i].res, w.b)) ok = false;
+        if (!ok) continue;
+        auto row_len = [&](BufRef r) -> int64_t {
+            return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)].row_len : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)].row_len
+                                                                                                               : plan.out_layout.row_len;
+        };
+        const int64_t ll = row_len(w.a), rl = row_len(w.b);
+        const int n2 = dn.dense_n;
+        // items a workgroup of the dense kernel stages at once (runtime.hip: prepare_step)
+        int ipb = 1;
+        if (dn.use_mfma) ipb = n2 <= 10 ? 4 : n2 == 11 ? 2 : 1;
+        else if (!dn.use_mfma16) ipb = std::max(256, 1 << (n2 - 4)) >> (n2 - 4);
+        const size_t scratch = size_t(ipb) * size_t(ll + rl) * elem;
+        const size_t images = size_t(ipb) * (size_t(dn.use_mfma && !dn.mfma32_pairs ? 2 : (dn.use_mfma || dn.use_mfma16) ? 4 : 2) << n2) * elem + 256;
+        if (scratch > 48 * 1024 || images + scratch > kLdsBytes - 1024 || w.u32_b.size() > 32768) continue;
+        // rows of the list -> components of the dense step's left image
+        std::vector<int32_t> map_of(size_t(row_len(buf)), -1);
+        for (size_t c = 0; c < dn.u32_a.size(); ++c) map_of[dn.u32_a[c] & 0xffffu] = int32_t(c);
+        dn.pre_row_map.clear();
+        dn.pre_row_scale.clear();
+        bool covered = true;
+        std::vector<uint32_t> row_start(1, 0u), entries;
+        std::vector<double> coeff;
+        std::vector<char> produced(dn.u32_a.size(), 0);
+        for (size_t row = 0; row < w.u32_b.size(); ++row) {
+            const int32_t c = map_of[w.u32_b[row]];
+            if (c < 0) continue;   // a component the dense product does not read (its grade is not wanted there)
+            produced[size_t(c)] = 1;
+            dn.pre_row_map.push_back(dn.u32_a[size_t(c)] & 0xffff0000u);
+            if (dn.scaled) dn.pre_row_scale.push_back(dn.coeff[size_t(c)]);
+            for (uint32_t e = w.u32_a[row]; e < w.u32_a[row + 1]; ++e) {
+                entries.push_back(w.u32_c[e]);
+                coeff.push_back(w.coeff[e]);
+            }
+            row_start.push_back(uint32_t(entries.size()));
+        }
+        for (char c : produced) covered = covered && c;
+        // rows of one length with +-1 coefficients (R X: n entries per row): [term][row] words, sign in bit 31
+        {
+            const size_t rows = row_start.size() - 1;
+            const uint32_t width = rows ? row_start[1] - row_start[0] : 0;
+            bool uniform = rows > 0 && width > 0;
+            for (size_t r = 0; uniform && r < rows; ++r) uniform = row_start[r + 1] - row_start[r] == width;
+            for (size_t e = 0; uniform && e < coeff.size(); ++e) uniform = coeff[e] == 1.0 || coeff[e] == -1.0;
+            for (size_t e = 0; uniform && e < entries.size(); ++e) uniform = (entries[e] & 0xffffu) < 0x8000u && (entries[e] >> 16) < 0x8000u;
+            if (uniform) {
+                std::vector<uint32_t> ell(entries.size());
+                for (size_t r = 0; r < rows; ++r)
+                    for (uint32_t t = 0; t < width; ++t) {
+                        const size_t e = size_t(row_start[r]) + t;
+                        ell[size_t(t) * rows + r] = entries[e] | (coeff[e] < 0.0 ? 0x80000000u : 0u);
+                    }
+                entries.swap(ell);
+                coeff.clear();
+                dn.pre_width = int(width);
+            }
+        }
+        dn.chained = 1;
+        dn.pre_a = w.a;
+        dn.pre_b = w.b;
+        dn.pre_canon_a = w.canon_a;
+        dn.pre_canon_b = w.canon_b;
+        dn.pre_row_start = std::move(row_start);
+        dn.pre_entries = std::move(entries);
+        dn.pre_coeff = std::move(coeff);
+        dn.pre_left_len = int(ll);
+        dn.pre_right_len = int(rl);
+        // components no row produces stay zero: the kernel zero-fills the image first unless every loaded component is covered
+        dn.left_full = dn.left_full && covered;
+        dn.left_contig = 0;   // general staging
+        dn.name += " <- " + w.name + " in LDS";
+        dn.n_entries += w.n_entries;
+        dn.a = BufRef{BufKind::NODE, -1};
+        plan.node_dead[size_t(buf.idx)] = 1;
+        w.kind = Step::ZERO;   // marks the list step for removal below
+        w.res = BufRef{BufKind::NODE, -1};
+    }
+    std::vector<Step> kept;
+    for (Step& t : plan.steps)
+        if (!(t.kind == Step::ZERO && t.res.kind == BufKind::NODE && t.res.idx < 0)) kept.push_back(std::move(t));
+    plan.steps = std::move(kept);
+}
+
 void build_plan(const gaast_program_desc& desc, Plan& plan) {
     if (desc.vec_space_dim < 0 || desc.vec_space_dim > GAAST_MAX_DIM) throw std::runtime_error("vec_space_dim out of range");
     if (desc.n_nodes <= 0 || desc.root < 0 || desc.root >= desc.n_nodes) throw std::runtime_error("bad node count / root");
@@ -1551,7 +1667,11 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
     for (size_t i = 0; i < plan.steps.size(); ++i)
         if (!lw.removed[i]) kept.push_back(std::move(plan.steps[i]));
     plan.steps = std::move(kept);
-    if (!try_fuse(plan)) uniform_csr_to_ell(plan);
+    plan.node_dead.assign(plan.node_buffers.size(), 0);
+    if (!try_fuse(plan)) {
+        chain_sparse_into_dense(plan);
+        uniform_csr_to_ell(plan);
+    }
 }
 
 }  // namespace gaast

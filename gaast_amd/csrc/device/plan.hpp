@@ -75,6 +75,25 @@ struct Step {
     int neg_lo_all = 0;    // vector-FMA kernel: the NEGLO instantiation (all four lo vectors square to -1)
     int degenerate = 0;
     int dense_n = 0;     // DENSE: dimension of the algebra the kernel runs in (the program's n, or n - 1: parity-pure operands)
+    // DENSE, chained (plan.cpp: chain_sparse_into_dense): the LEFT operand is the result of a short comp-mul list over two other
+    // rows (eval.rs:61-86 with a cached operand that nothing else reads: R X in R X ~R).  The list is evaluated in LDS while
+    // the dense kernel stages its operands -- reference order, same roundings -- and the intermediate never goes through HBM.
+    int chained = 0;
+    BufRef pre_a, pre_b;                 // the list's operand rows
+    int pre_canon_a = 0, pre_canon_b = 0;
+    std::vector<uint32_t> pre_row_start; // rows + 1
+    std::vector<uint32_t> pre_entries;   // left offset | right offset << 16
+    std::vector<double> pre_coeff;
+    std::vector<uint32_t> pre_row_map;   // per row: image position << 16 | negate << 31 (the left_map word of the component the row produces)
+    std::vector<double> pre_row_scale;   // per row (rescaled basis), else empty
+    int pre_left_len = 0, pre_right_len = 0;
+    int pre_width = 0;                   // > 0: rows of one length with +-1 coefficients: pre_entries is [term][row], sign in bit 31
+    size_t pre_scratch_off = 0;          // bytes: where the list's operand rows sit in the kernel's LDS (after its images)
+    void* d_pre_row_start = nullptr;
+    void* d_pre_entries = nullptr;
+    void* d_pre_coeff = nullptr;
+    void* d_pre_row_map = nullptr;
+    void* d_pre_row_scale = nullptr;
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)
@@ -124,6 +143,7 @@ struct Plan {
     std::vector<std::vector<double>> const_rows;
     std::vector<Layout> input_layouts;
     std::vector<Layout> node_buffers;  // cache buffers other than the root's
+    std::vector<char> node_dead;       // ... that a chained product made unnecessary (never allocated)
     Layout out_layout;
     std::vector<Step> steps;
     int error = GAAST_OK;              // what the reference would have panicked with, at eval

@@ -98,7 +98,8 @@ namespace {
 // device tables and hiprtc modules of a plan (also called before a plan is rebuilt)
 void release_plan_resources(Plan& plan) {
     for (Step& s : plan.steps) {
-        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b, &s.d_coeff_c}) {
+        for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b, &s.d_coeff_c, &s.d_pre_row_start, &s.d_pre_entries,
+                         &s.d_pre_coeff, &s.d_pre_row_map, &s.d_pre_row_scale}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -344,7 +345,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
 
 template <typename T>
 int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, const Layout& la,
-             const Layout& lb, int64_t batch, int n) {
+             const Layout& lb, int64_t batch, int n, const Bound& pre_a = Bound{nullptr, 0}, const Bound& pre_b = Bound{nullptr, 0}) {
     switch (s.kind) {
     case Step::ZERO: return GAAST_OK;  // handled by the caller (needs the row length)
     case Step::AXPY: {
@@ -511,6 +512,27 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         }
         p.left_signs = s.left_signs;
         p.out_signs = s.out_signs;
+        p.pre_left = p.pre_right = nullptr;
+        p.pre_entries = nullptr;
+        if (s.chained) {   // the left operand is a comp-mul list over two other rows, evaluated in LDS while staging
+            p.pre_left = static_cast<const T*>(pre_a.ptr);
+            p.pre_right = static_cast<const T*>(pre_b.ptr);
+            p.pre_left_stride = pre_a.stride;
+            p.pre_right_stride = pre_b.stride;
+            p.pre_left_len = s.pre_left_len;
+            p.pre_right_len = s.pre_right_len;
+            p.pre_canon_left = s.pre_canon_a;
+            p.pre_canon_right = s.pre_canon_b;
+            p.pre_row_start = static_cast<const uint32_t*>(s.d_pre_row_start);
+            p.pre_entries = static_cast<const uint32_t*>(s.d_pre_entries);
+            p.pre_coeff = static_cast<const T*>(s.d_pre_coeff);
+            p.pre_row_map = static_cast<const uint32_t*>(s.d_pre_row_map);
+            p.pre_row_scale = static_cast<const T*>(s.d_pre_row_scale);
+            p.pre_rows = int(s.pre_row_map.size());
+            p.pre_width = s.pre_width;
+            p.pre_scratch = int(s.pre_scratch_off / sizeof(T));
+            p.left_count = 0;
+        }
         p.left_scale = s.scaled ? static_cast<const T*>(s.d_coeff) : nullptr;
         p.right_scale = s.scaled ? static_cast<const T*>(s.d_coeff_b) : nullptr;
         p.out_scale = s.scaled ? static_cast<const T*>(s.d_coeff_c) : nullptr;
@@ -737,6 +759,32 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
         const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;   // parity-pure products run in Cl(n - 1)
         if (int st = plan.dtype == GAAST_F32 ? prepare_step<float>(s, la, lb, step_n) : prepare_step<double>(s, la, lb, step_n))
             return st;
+        if (s.chained) {
+            // the list's operand rows of every item a workgroup stages at once, after the kernel's own images
+            s.pre_scratch_off = (s.lds + 15) / 16 * 16;
+            const size_t items = size_t(s.items_per_block > 0 ? s.items_per_block : 1);
+            s.lds = s.pre_scratch_off + items * size_t(s.pre_left_len + s.pre_right_len) * dtype_size(plan.dtype);
+            if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "chained product does not fit in LDS (" + s.name + ")");
+            for (int v = 0; v < 3; ++v)
+                if (s.kern[v])
+                    if (int st = allow_lds(s.kern[v], s.lds)) return st;
+            if (s.blocks_per_cu > 0)
+                if (int st = resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu)) return st;
+            if (s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
+            if (s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
+            if (int st = upload_vec(s.pre_row_start, &s.d_pre_row_start)) return st;
+            if (int st = upload_vec(s.pre_entries, &s.d_pre_entries)) return st;
+            if (int st = upload_vec(s.pre_row_map, &s.d_pre_row_map)) return st;
+            auto upload_t = [&](const std::vector<double>& v, void** dptr) -> int {
+                if (plan.dtype == GAAST_F32) {
+                    std::vector<float> cf(v.begin(), v.end());
+                    return upload_vec(cf, dptr);
+                }
+                return upload_vec(v, dptr);
+            };
+            if (int st = upload_t(s.pre_coeff, &s.d_pre_coeff)) return st;
+            if (int st = upload_t(s.pre_row_scale, &s.d_pre_row_scale)) return st;
+        }
         if (s.a.idx >= 0 && s.a.kind == BufKind::INPUT) plan.slot_used[size_t(s.a.idx)] = 1;
         if (s.b.idx >= 0 && s.b.kind == BufKind::INPUT) plan.slot_used[size_t(s.b.idx)] = 1;
         for (const Step::FusedInput& fi : s.fused_inputs) plan.slot_used[size_t(fi.slot)] = 1;
@@ -992,9 +1040,12 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         if (!prog->scratch.empty()) HIP_TRY(hipStreamSynchronize(g_stream));  // launches may still read the old ones
         for (gaast_hip_mv_t m : prog->scratch) mv_free_impl(m);
         prog->scratch.clear();
-        for (const Layout& l : plan.node_buffers) {
+        for (size_t bi = 0; bi < plan.node_buffers.size(); ++bi) {
+            const Layout& l = plan.node_buffers[bi];
             gaast_hip_mv_t m = nullptr;
-            if (int st = mv_alloc_impl(l.dim, l.mask, count, plan.dtype, &m)) return st;
+            // a cache buffer a chained product made unnecessary is never allocated
+            const bool dead = bi < plan.node_dead.size() && plan.node_dead[bi];
+            if (int st = mv_alloc_impl(l.dim, l.mask, dead ? 0 : count, plan.dtype, &m)) return st;
             prog->scratch.push_back(m);
         }
         prog->scratch_batch = count;
@@ -1030,8 +1081,14 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         if (s.a.idx >= 0) a = resolve(s.a, &la);
         if (s.b.idx >= 0) b = resolve(s.b, &lb);
         const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;
-        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, step_n)
-                                               : run_step<double>(s, res, a, b, la, lb, count, step_n);
+        Bound pa{nullptr, 0}, pb{nullptr, 0};
+        if (s.chained) {
+            Layout unused;
+            pa = resolve(s.pre_a, &unused);
+            pb = resolve(s.pre_b, &unused);
+        }
+        const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, step_n, pa, pb)
+                                               : run_step<double>(s, res, a, b, la, lb, count, step_n, pa, pb);
         if (st != GAAST_OK) return st;
     }
     return GAAST_OK;

@@ -142,6 +142,7 @@ typedef struct gaast_input_desc {
  * GAAST_ERR_UNIMPLEMENTED exactly where the reference panics. */
 #define GAAST_FLAG_EXP_LOG 0x100u
 #define GAAST_FLAG_DEBUG_LDS_12K 0x400u /* hiprtc-specialised kernels: 12 KiB instead of 10 KiB of LDS per wave for the row transposition (A/B testing) */
+#define GAAST_FLAG_DEBUG_NO_CHAIN 0x800u /* a sparse product that only feeds a dense product stays a launch of its own (default: evaluated in the dense kernel's LDS staging; A/B testing) */
 #define GAAST_FLAG_NO_COALESCE 0x200u  /* hiprtc-specialised kernels: every lane reads / writes its own row (no LDS-transposed coalesced row I/O; A/B testing) */
 
 typedef struct gaast_program_desc {

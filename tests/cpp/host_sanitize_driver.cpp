@@ -350,6 +350,20 @@ int main() {
         const double mix11[11] = {1, -1, 1, 1, 0, 1, -1, 1, -1, 1, 1};
         dense_tables_agree_with_the_list(11, mix11, GAAST_F32, 0, "parity-pure n=11 -> mfma32p<10> odd x even", "odd x even", OD & full_mask(11), EV & full_mask(11));
     }
+    {   // chained products: R X ~R at n = 8, 9, 10 -- the sparse product R X moves into the dense step's LDS staging
+        const double m63[9] = {1, 1, 1, 1, 1, 1, -1, -1, -1};
+        for (int n : {8, 9, 10}) {
+            uint64_t even = 0;
+            for (int k = 0; k <= n; k += 2) even |= uint64_t(1) << k;
+            gaast_expr_t r = gaast_expr_input(0, even, n), x = gaast_expr_input(1, 0x2, n);
+            gaast_expr_t e = gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC);
+            char what[64];
+            std::snprintf(what, sizeof what, "sandwich n=%d chained", n);
+            lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, 0, what, "<- product_csr");
+            std::snprintf(what, sizeof what, "sandwich n=%d two launches", n);
+            lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, GAAST_FLAG_DEBUG_NO_CHAIN, what, "product_csr");
+        }
+    }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {
         std::printf("%d failures\n", failures);

@@ -330,3 +330,36 @@ def test_parity_pure_with_a_general_metric_and_partial_grades():
            batch=3, seed=520, right_grades=ODD(9), eps_factor=8, exact_order_too=True, label_has="even x odd in Cl(8)")
     _check(10, [1.0] * 10, [0, 2, 4, 6], [(ga.F64, 0, "product_dense_mfma[", "k_gp_mfma16x4<double,false,9,")], batch=2, seed=521,
            right_grades=EVEN(10), label_has="even x even in Cl(9)")
+
+
+@pytest.mark.parametrize("n,metric", [(8, [1.0] * 8), (9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (9, [2.0, 1.0, -0.5, 1.0, 1.0, 3.0, -1.0, 1.0, 0.25])])
+def test_rotor_sandwich_beyond_the_fused_slab_is_one_launch(n, metric):
+    """BASELINE configs[4]'s pipeline R X ~R (eval.rs:61-86 with the cached operand R X, README.md:62-67) where it no longer fits
+    a fused small-program kernel: the sparse product R X (n 2^(n-1) entries) is evaluated in the LDS staging of the dense
+    product (R X) ~R (odd x even: Cl(n - 1)) -- ONE launch, the intermediate never goes through HBM.  The list keeps the
+    reference's order and roundings, so the result is bit-identical to the two-launch plan (GAAST_FLAG_DEBUG_NO_CHAIN), and
+    within 4 eps sum|terms| of the second product (8 eps: general metric) of the oracle; GAAST_FLAG_EXACT_ORDER: bit-exact."""
+    even = [k for k in range(n + 1) if k % 2 == 0]
+    build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, even, n), B.input(1, [1], n))
+    batch = 5
+    rng = np.random.default_rng(600 + n)
+    rows = {0: rows_of(n, even, batch, rng), 1: rows_of(n, [1], batch, rng)}
+    alg = metric if any(m != 1.0 for m in metric) else n
+    want, wmask = oracle_eval_batch(build, alg, rows, batch)
+    rx, rxmask = oracle_eval_batch(lambda B: B.input(0, even, n) * B.input(1, [1], n), alg, rows, batch)
+    got, mask, spec = hip_eval_batch(build, alg, rows, batch)
+    assert mask == wmask
+    assert len(spec.launches()) == 1 and "product_dense" in spec.launches()[0] and "<- product_csr" in spec.launches()[0], spec.launches()
+    two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN)
+    assert len(spec2.launches()) == 2, spec2.launches()
+    assert np.array_equal(got, two)                      # the very bits of the two-launch plan
+    general = any(m not in (1.0, -1.0, 0.0) for m in metric)
+    odd = [k for k in range(n + 1) if (rxmask >> k) & 1]
+    og = [k for k in range(n + 1) if (wmask >> k) & 1]
+    for i in range(batch):
+        S = abs_terms_bound(n, row_to_bits(n, odd, rx[i]), row_to_bits(n, even, rows[1 - 1][i]), metric if general else None)
+        bound = (8 if general else 4) * 2.0 ** -52 * bits_to_row(n, og, S) + 1e-300
+        err = np.abs(got[i] - want[i])
+        assert np.all(err <= bound), (i, float((err / bound).max()))
+    exact, _, spec3 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+    assert np.array_equal(exact, want)
