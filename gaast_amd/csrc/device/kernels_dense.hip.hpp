@@ -426,7 +426,7 @@ struct BlockStep<double> {
 };
 
 // NEGLO: all four lo basis vectors square to -1 (else: all four to +1)
-template <typename T, bool DEGENERATE, int THREADS, bool NEGLO, bool SCALED = false>
+template <typename T, bool DEGENERATE, int THREADS, bool NEGLO, bool SCALED = false, bool CHAINED = false>
 __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
     // SCALED (a general diagonal metric, DenseArgs::left_scale ...): a separate instantiation, so that the +-1 / 0 kernels
     // carry none of its code or registers
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_dense(DenseArgs<T> p) {
                 for (int i = tid; i < nitems * item_stride; i += THREADS) smem[i] = zero;
                 __syncthreads();
             }
-            if (p.pre_entries)
+            if constexpr (CHAINED)   // (its own instantiation: the plain kernels carry none of this code or its registers)
                 stage_from_list<T, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
             else
                 stage_operands<T, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
@@ -547,7 +547,7 @@ __device__ __forceinline__ int mfma_b_pos(int m) {
     return (x << 5) | (((lq ^ (x >> 1)) & 7) << 2) | ((k >> 1) & 3);
 }
 
-template <bool DEGENERATE, int THREADS, bool SCALED = false>
+template <bool DEGENERATE, int THREADS, bool SCALED = false, bool CHAINED = false>
 __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
     const float* const left_scale = SCALED ? p.left_scale : nullptr;
     const float* const right_scale = SCALED ? p.right_scale : nullptr;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_mfma32(DenseArgs<float> p) {
         __syncthreads();
     }
     {
-        if (p.pre_entries)
+        if constexpr (CHAINED)   // (its own instantiation: the plain kernels carry none of this code or its registers)
             stage_from_list<float, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
         else
             stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
@@ -712,7 +712,7 @@ __device__ __forceinline__ constexpr int mfma16_k(int t) {
 // current one; barriers between the phases wait for LDS traffic only (lds_barrier).
 // (The second launch bound, two workgroups per CU, only changes the compiler's scheduling here -- every instantiation
 //  stays under the 256 registers of two waves per SIMD anyway: n = 10 / 11 gain 7-9 % with it, n = 12 LOSES 6 %.)
-template <bool DEGENERATE, int NDIM, bool SCALED = false>
+template <bool DEGENERATE, int NDIM, bool SCALED = false, bool CHAINED = false>
 __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_gp_mfma32p(DenseArgs<float> p) {
     const float* const left_scale = SCALED ? p.left_scale : nullptr;
     const float* const right_scale = SCALED ? p.right_scale : nullptr;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
     static_assert(MPR * ROWS == 8, "eight 16-byte pieces per thread and group");
     const int tid = threadIdx.x;
     const int64_t num_groups = (p.batch + IPB - 1) / IPB;
-    const bool fast = !SCALED && p.left_contig && p.right_contig && p.left_full && p.right_full;   // (a rescaled basis: general staging)
+    const bool fast = !SCALED && !CHAINED && p.left_contig && p.right_contig && p.left_full && p.right_full;   // (a rescaled basis: general staging)
 
     if (tid < 16) smem[IPB * item_stride + tid] = 0.f;   // the B "block" of a vanishing contribution
 
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(NDIM == 13 ? 512 : 256, NDIM <= 11 ? 2 : 1) void k_
                 for (int e = tid; e < nitems * item_stride; e += THREADS) smem[e] = 0.f;
                 lds_barrier<THREADS>();
             }
-            if (p.pre_entries)
+            if constexpr (CHAINED)   // (its own instantiation: the plain kernels carry none of this code or its registers)
                 stage_from_list<float, THREADS>(p, item0, nitems, smem, item_stride, smem + p.pre_scratch, tid);
             else
                 stage_operands<float, THREADS>(p.left + item0 * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
@@ -1080,10 +1080,10 @@ struct Mfma16x4<float> {
 // into +0.0, and in these kernels a zero operand of either sign contributes +-0 to a sum that starts from +0.0 and is
 // rounded to nearest, which leaves every sum -- also an all-zero one: (+0) + (-0) = +0 -- bit for bit what it would be
 // (tests/test_gpu_dense_oracle.py::test_negative_zero_operands_leave_no_trace).
-template <typename T, bool DEGENERATE, int NDIM, int MODE, bool SCALED = false>
+template <typename T, bool DEGENERATE, int NDIM, int MODE, bool SCALED = false, bool CHAINED = false>
 __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p) {
     constexpr bool FAST = MODE >= 1;
-    static_assert(!(SCALED && MODE != 0), "a rescaled basis runs on the general staging and stores");
+    static_assert(!((SCALED || CHAINED) && MODE != 0), "a rescaled basis / a chained product runs on the general staging and stores");
     const T* const left_scale = SCALED ? p.left_scale : nullptr;
     const T* const right_scale = SCALED ? p.right_scale : nullptr;
     const T* const out_scale = SCALED ? p.out_scale : nullptr;
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p
                 for (int e = tid; e < 4 * N + PAD_A; e += THREADS) smem[e] = T(0);
                 lds_barrier<THREADS>();
             }
-            if (p.pre_entries)
+            if constexpr (CHAINED)   // (its own instantiation: the plain kernels carry none of this code or its registers)
                 stage_from_list<T, THREADS>(p, item, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid);
             else
                 stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,

@@ -176,11 +176,22 @@ int resident_blocks(const void* kern, int threads, size_t lds, int* per_cu) {
 // block size, dynamic LDS, persistent grid.  A step no kernel of this back end can run (operands beyond the LDS
 // budget) makes program_create fail with UNIMPLEMENTED: an eval then either runs every step or none.
 // ------------------------------------------------------------------------------------------
+// picks the (SCALED, CHAINED) instantiation of a dense kernel family: f(std::bool_constant<SC>, std::bool_constant<CH>)
+template <typename F>
+auto pick_variant(bool scaled, bool chained, F&& f) {
+    if (scaled && chained) return f(std::true_type{}, std::true_type{});
+    if (scaled) return f(std::true_type{}, std::false_type{});
+    if (chained) return f(std::false_type{}, std::true_type{});
+    return f(std::false_type{}, std::false_type{});
+}
+
 template <typename T>
 int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
     constexpr bool is_f64 = std::is_same<T, double>::value;
     const std::string tn = is_f64 ? "double" : "float";
     const std::string dg = s.degenerate ? "true" : "false";
+    // (SCALED, CHAINED) template arguments as they appear in the kernel's name: ",true" = rescaled basis, ",false,true" = chained
+    const std::string vs = s.chained ? (s.scaled ? ",true,true" : ",false,true") : (s.scaled ? ",true" : "");
     switch (s.kind) {
     case Step::PRODUCT_CSR: {
         const size_t per_item = size_t(la.row_len + lb.row_len) * sizeof(T);
@@ -251,31 +262,29 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                     s.lds = (size_t(s.items_per_block) * size_t(4 << n) + 16) * sizeof(float);
                     if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
                     using KernD = void (*)(DenseArgs<float>);
-                    auto pickp = [&](auto sc) -> KernD {
-                        constexpr bool SC = decltype(sc)::value;
-                        return n == 10   ? (s.degenerate ? &k_gp_mfma32p<true, 10, SC> : &k_gp_mfma32p<false, 10, SC>)
-                               : n == 11 ? (s.degenerate ? &k_gp_mfma32p<true, 11, SC> : &k_gp_mfma32p<false, 11, SC>)
-                               : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12, SC> : &k_gp_mfma32p<false, 12, SC>)
-                                         : (s.degenerate ? &k_gp_mfma32p<true, 13, SC> : &k_gp_mfma32p<false, 13, SC>);
-                    };
-                    const KernD kernp = s.scaled ? pickp(std::true_type{}) : pickp(std::false_type{});
+                    const KernD kernp = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
+                        constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
+                        return n == 10   ? (s.degenerate ? &k_gp_mfma32p<true, 10, SC, CH> : &k_gp_mfma32p<false, 10, SC, CH>)
+                               : n == 11 ? (s.degenerate ? &k_gp_mfma32p<true, 11, SC, CH> : &k_gp_mfma32p<false, 11, SC, CH>)
+                               : n == 12 ? (s.degenerate ? &k_gp_mfma32p<true, 12, SC, CH> : &k_gp_mfma32p<false, 12, SC, CH>)
+                                         : (s.degenerate ? &k_gp_mfma32p<true, 13, SC, CH> : &k_gp_mfma32p<false, 13, SC, CH>);
+                    });
                     s.kern[0] = reinterpret_cast<const void*>(kernp);
-                    s.hip_kernel = "k_gp_mfma32p<" + dg + "," + std::to_string(n) + (s.scaled ? ",true>" : ">");
+                    s.hip_kernel = "k_gp_mfma32p<" + dg + "," + std::to_string(n) + vs + ">";
                     if (int st = allow_lds(s.kern[0], s.lds)) return st;
                     return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
                 }
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
                 using KernD = void (*)(DenseArgs<float>);
-                auto pick32 = [&](auto sc) -> KernD {
-                    constexpr bool SC = decltype(sc)::value;
-                    return s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256, SC> : &k_gp_mfma32<false, 256, SC>)
-                           : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512, SC> : &k_gp_mfma32<false, 512, SC>)
-                                              : (s.degenerate ? &k_gp_mfma32<true, 1024, SC> : &k_gp_mfma32<false, 1024, SC>);   // n = 14: 16 waves, 128 KiB of LDS
-                };
-                const KernD kern = s.scaled ? pick32(std::true_type{}) : pick32(std::false_type{});
+                const KernD kern = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
+                    constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
+                    return s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256, SC, CH> : &k_gp_mfma32<false, 256, SC, CH>)
+                           : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512, SC, CH> : &k_gp_mfma32<false, 512, SC, CH>)
+                                              : (s.degenerate ? &k_gp_mfma32<true, 1024, SC, CH> : &k_gp_mfma32<false, 1024, SC, CH>);   // n = 14: 16 waves, 128 KiB of LDS
+                });
                 s.kern[0] = reinterpret_cast<const void*>(kern);
-                s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + (s.scaled ? ",true>" : ">");
+                s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + vs + ">";
                 return allow_lds(s.kern[0], s.lds);
             }
         }
@@ -298,21 +307,22 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
                 }
             };
-            auto pick_scaled = [&]() -> KernD {   // a rescaled basis (general diagonal metric): general staging and stores only
+            // a rescaled basis (general diagonal metric) / a chained product: general staging and stores only
+            const KernD kd = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
+                constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
                 switch (n) {
-                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, 0, true> : &k_gp_mfma16x4<T, false, 8, 0, true>;
-                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, 0, true> : &k_gp_mfma16x4<T, false, 9, 0, true>;
-                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, 0, true> : &k_gp_mfma16x4<T, false, 10, 0, true>;
-                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, 0, true> : &k_gp_mfma16x4<T, false, 11, 0, true>;
-                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, 0, true> : &k_gp_mfma16x4<T, false, 12, 0, true>;
+                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, 0, SC, CH> : &k_gp_mfma16x4<T, false, 8, 0, SC, CH>;
+                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, 0, SC, CH> : &k_gp_mfma16x4<T, false, 9, 0, SC, CH>;
+                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, 0, SC, CH> : &k_gp_mfma16x4<T, false, 10, 0, SC, CH>;
+                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, 0, SC, CH> : &k_gp_mfma16x4<T, false, 11, 0, SC, CH>;
+                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, 0, SC, CH> : &k_gp_mfma16x4<T, false, 12, 0, SC, CH>;
                 }
-            };
-            const KernD kd = s.scaled ? pick_scaled() : pick(std::integral_constant<int, 0>{}), kf = pick(std::integral_constant<int, 1>{}),
-                        kw = pick(std::integral_constant<int, 2>{});
+            });
+            const KernD kf = pick(std::integral_constant<int, 1>{}), kw = pick(std::integral_constant<int, 2>{});
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
             s.kern[2] = reinterpret_cast<const void*>(kw);
-            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + (s.scaled ? ",0,true>" : ",0|1|2>");   // staging / store mode: by alignment at launch
+            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + ((s.scaled || s.chained) ? ",0" + vs + ">" : ",0|1|2>");   // staging / store mode: by alignment at launch
             for (int v = 0; v < 3; ++v)
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
@@ -324,17 +334,16 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         if (s.lds > g_max_lds)
             return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product of dimension " + std::to_string(n) + " does not fit in LDS");
         using KernD = void (*)(DenseArgs<T>);
-        auto pickd = [&](auto sc) -> KernD {
-            constexpr bool SC = decltype(sc)::value;
+        const KernD kern = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
+            constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
             if (s.neg_lo_all)
-                return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, true, SC> : &k_gp_dense<T, false, 256, true, SC>)
-                                        : (s.degenerate ? &k_gp_dense<T, true, 512, true, SC> : &k_gp_dense<T, false, 512, true, SC>);
-            return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false, SC> : &k_gp_dense<T, false, 256, false, SC>)
-                                    : (s.degenerate ? &k_gp_dense<T, true, 512, false, SC> : &k_gp_dense<T, false, 512, false, SC>);
-        };
-        const KernD kern = s.scaled ? pickd(std::true_type{}) : pickd(std::false_type{});
+                return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, true, SC, CH> : &k_gp_dense<T, false, 256, true, SC, CH>)
+                                        : (s.degenerate ? &k_gp_dense<T, true, 512, true, SC, CH> : &k_gp_dense<T, false, 512, true, SC, CH>);
+            return s.threads == 256 ? (s.degenerate ? &k_gp_dense<T, true, 256, false, SC, CH> : &k_gp_dense<T, false, 256, false, SC, CH>)
+                                    : (s.degenerate ? &k_gp_dense<T, true, 512, false, SC, CH> : &k_gp_dense<T, false, 512, false, SC, CH>);
+        });
         s.kern[0] = reinterpret_cast<const void*>(kern);
-        s.hip_kernel = "k_gp_dense<" + tn + "," + dg + "," + std::to_string(s.threads) + "," + (s.neg_lo_all ? "true" : "false") + (s.scaled ? ",true>" : ">");
+        s.hip_kernel = "k_gp_dense<" + tn + "," + dg + "," + std::to_string(s.threads) + "," + (s.neg_lo_all ? "true" : "false") + vs + ">";
         if (int st = allow_lds(s.kern[0], s.lds)) return st;
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
