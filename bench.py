@@ -233,12 +233,38 @@ def cpu_baseline(wl, budget_s=12.0):
         if ok:
             all_cores = {"value": cores * per_worker / (wall * scale), "unit": "products/s", "cores": cores,
                          "sample": f"{cores} forked workers x {per_worker} evaluations, {wall:.1f} s wall"}
+    # `cpu-packed-1t` (the same loop over 16-byte packed entries on flat rows: how much of the reference's
+    # time is table traffic) and `cpu-packed-allcores` (the batch split over threads: the fair CPU ceiling)
+    packed = None
+    pk = spec.packed_root_product()
+    if pk is not None:
+        hnd, n_ent, pll, prl, pol = pk
+        t_item = max(1e-7, n_ent * 1.2e-9)
+        pb1 = max(2, min(1 << 16, int(0.25 * budget_s / t_item)))
+        dbl = C.POINTER(C.c_double)
+        def run(pbatch, threads):
+            la = np.ascontiguousarray(rng.uniform(-1, 1, (pbatch, pll)))
+            ra = np.ascontiguousarray(rng.uniform(-1, 1, (pbatch, prl)))
+            oa = np.empty((pbatch, pol))
+            sec = L.og_packed_eval_batch(hnd, n_ent, la.ctypes.data_as(dbl), pll, ra.ctypes.data_as(dbl), prl,
+                                         oa.ctypes.data_as(dbl), pol, pbatch, threads)
+            return pbatch / (sec * scale)
+        v1 = run(pb1, 1)
+        packed = {"cpu-packed-1t": {"value": v1, "unit": "products/s", "cores": 1,
+                                    "sample": note + f"{pb1} items, {n_ent} entries of 16 bytes (u32 left, u32 right, u32 out, f32 coeff) on flat rows, same order and roundings"}}
+        if cores > 1:
+            pbn = pb1 * cores
+            packed["cpu-packed-allcores"] = {"value": run(pbn, cores), "unit": "products/s", "cores": cores,
+                                             "sample": note + f"{pbn} items over {cores} threads (contiguous item ranges)"}
+        L.og_packed_free(hnd)
     out = {"value": 1.0 / per_item, "unit": "products/s", "cores": 1, "kind": "port",
            "sample": note + f"{items} evaluations of the oracle's eval.rs loop (f64, 56-byte AoS entries, "
                             f"per-eval allocations included), {dt * 1e3:.2f} ms each; table build {t_spec:.1f} s excluded; "
                             f"host has {cores} cores"}
     if all_cores:
         out["all_cores"] = all_cores
+    if packed:
+        out["variants"] = packed      # cpu-ref-1t is `value`; these are the packed-table variants
     return out
 
 

@@ -678,6 +678,15 @@ int gaast_hip_init(const int* device_ids, int n_dev) {
     if (g_max_lds > 160 * 1024) g_max_lds = 160 * 1024;
     g_device = device_ids[0];
     g_stream = nullptr;
+    // Load the library's code object NOW (HIP loads a fat binary lazily, at the first launch or attribute query of one of its
+    // kernels): twice in round 3 a process that had compiled kernels through hiprtc first and launched its first statically
+    // compiled kernel afterwards (tests/test_gpu_explog.py run alone: three hiprtc programs, then k_axpy_map / k_exp_log)
+    // ended in a silent abort() inside that first launch; with the static code object resident before hiprtc is ever
+    // initialised the order that preceded both aborts cannot occur.
+    {
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_flip<double>)));
+    }
     g_init = true;
     return GAAST_OK;
 }

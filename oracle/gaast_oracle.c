@@ -1315,3 +1315,90 @@ int og_eval_batch(const og_spec *s, int mode, og_mv **inputs, const double **in_
     }
     return OG_OK;
 }
+
+
+/* ---- cpu-packed baselines ------------------------------------------------------------------- */
+#include <pthread.h>
+#include <time.h>
+
+static size_t row_offset_of(og_gradeset gs, int dim, size_t grade) {
+    size_t off = 0;
+    for (size_t k = 0; k < grade; ++k)
+        if (og_gs_contains(gs, (int)k)) off += (size_t)og_n_choose_k((uint64_t)dim, (uint64_t)k);
+    return off;
+}
+static size_t row_len_of(og_gradeset gs, int dim) {
+    size_t len = 0;
+    for (size_t k = 0; k <= (size_t)dim; ++k)
+        if (og_gs_contains(gs, (int)k)) len += (size_t)og_n_choose_k((uint64_t)dim, (uint64_t)k);
+    return len;
+}
+
+size_t og_pack_root_product(const og_spec *s, og_packed_mul **out, size_t *left_len, size_t *right_len, size_t *out_len) {
+    const gnode *root = &s->nodes[s->root];
+    if (root->kind != OG_N_PRODUCT) return 0;
+    const gnode *l = &s->nodes[root->child0], *r = &s->nodes[root->child1];
+    if (l->kind != OG_N_GRADED_OBJ || r->kind != OG_N_GRADED_OBJ) return 0;
+    const int dim = root->vec_space_dim;
+    og_packed_mul *p = (og_packed_mul *)malloc(sizeof(og_packed_mul) * (root->n_muls ? root->n_muls : 1));
+    if (!p) return 0;
+    /* operand rows are laid out by the grades the operands' minimal sets hold (what eval.rs copies into its cache buffers) */
+    for (size_t e = 0; e < root->n_muls; ++e) {
+        const og_comp_mul *m = &root->muls[e];
+        p[e].left = (uint32_t)(row_offset_of(l->minimal, dim, m->left_grade) + m->left_index);
+        p[e].right = (uint32_t)(row_offset_of(r->minimal, dim, m->right_grade) + m->right_index);
+        p[e].out = (uint32_t)(row_offset_of(root->minimal, dim, m->result_grade) + m->result_index);
+        p[e].coeff = (float)m->coeff;
+    }
+    *out = p;
+    *left_len = row_len_of(l->minimal, dim);
+    *right_len = row_len_of(r->minimal, dim);
+    *out_len = row_len_of(root->minimal, dim);
+    return root->n_muls;
+}
+
+void og_packed_free(og_packed_mul *p) { free(p); }
+
+typedef struct {
+    const og_packed_mul *muls;
+    size_t n, ll, rl, ol;
+    const double *left, *right;
+    double *out;
+    int64_t first, last;
+} packed_job;
+
+static void *packed_worker(void *arg) {
+    const packed_job *j = (const packed_job *)arg;
+    for (int64_t it = j->first; it < j->last; ++it) {
+        const double *l = j->left + (size_t)it * j->ll, *r = j->right + (size_t)it * j->rl;
+        double *o = j->out + (size_t)it * j->ol;
+        for (size_t c = 0; c < j->ol; ++c) o[c] = 0.0;            /* init_null_mv */
+        for (size_t e = 0; e < j->n; ++e) {                       /* eval.rs:77-83 */
+            const og_packed_mul *m = &j->muls[e];
+            o[m->out] += l[m->left] * r[m->right] * (double)m->coeff;
+        }
+    }
+    return NULL;
+}
+
+double og_packed_eval_batch(const og_packed_mul *muls, size_t n, const double *left, size_t left_len, const double *right,
+                            size_t right_len, double *out, size_t out_len, int64_t batch, int threads) {
+    if (threads < 1) threads = 1;
+    if ((int64_t)threads > batch) threads = (int)(batch > 0 ? batch : 1);
+    packed_job *jobs = (packed_job *)malloc(sizeof(packed_job) * (size_t)threads);
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int64_t per = (batch + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (packed_job){muls, n, left_len, right_len, out_len, left, right, out, t * per, (t + 1) * per < batch ? (t + 1) * per : batch};
+        if (threads == 1) packed_worker(&jobs[t]);
+        else pthread_create(&tid[t], NULL, packed_worker, &jobs[t]);
+    }
+    if (threads > 1)
+        for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(jobs);
+    free(tid);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -191,6 +191,23 @@ int og_eval_batch(const og_spec *s, int mode, og_mv **inputs, const double **in_
 void og_product_loop(const og_comp_mul *muls, size_t n, double *const *left, double *const *right,
                      double **res);
 
+/* ---- cpu-packed baselines (`cpu-packed-1t`, `cpu-packed-allcores`) ----
+ * The same loop as eval.rs:77-83 (`res[o] += left[l] * right[r] * coeff`, sequential, the reference's order) over 16-byte
+ * PACKED entries on flat graded rows instead of the reference's 56-byte {6 x usize, f64}: shows how much of the reference's
+ * time is table traffic, and -- with the batch split over threads -- the fair CPU ceiling of batched evaluation.  Bench
+ * infrastructure only (never a checker: the literal og_eval above is). */
+typedef struct og_packed_mul {
+    uint32_t left, right, out; /* offsets in the operands' / result's graded rows (grades ascending, concatenated) */
+    float coeff;               /* +-1 / 0 / metric products: exact in f32 for the benchmarked +-1 metrics */
+} og_packed_mul;
+/* packs the comp-mul list of the ROOT product of `s` (both operands GradedObj leaves); returns the entry count, 0 on
+ * failure; *out is malloc'ed (free with og_packed_free) */
+size_t og_pack_root_product(const og_spec *s, og_packed_mul **out, size_t *left_len, size_t *right_len, size_t *out_len);
+void og_packed_free(og_packed_mul *p);
+/* `batch` items (rows item-major), `threads` worker threads over contiguous item ranges; returns wall seconds */
+double og_packed_eval_batch(const og_packed_mul *muls, size_t n, const double *left, size_t left_len, const double *right,
+                            size_t right_len, double *out, size_t out_len, int64_t batch, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,11 @@ def lib():
                                C.POINTER(dbl), C.c_size_t]),
         "og_product_loop": (None, [C.POINTER(CompMulC), C.c_size_t, C.POINTER(C.POINTER(dbl)),
                                    C.POINTER(C.POINTER(dbl)), C.POINTER(C.POINTER(dbl))]),
+        # cpu-packed baselines: bench infrastructure
+        "og_pack_root_product": (C.c_size_t, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "og_packed_free": (None, [vp]),
+        "og_packed_eval_batch": (C.c_double, [vp, C.c_size_t, C.POINTER(dbl), C.c_size_t, C.POINTER(dbl), C.c_size_t,
+                                              C.POINTER(dbl), C.c_size_t, i64, ci]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -435,6 +440,16 @@ class SpecializedAst:
         if st != OG_OK:
             raise OraclePanic(st, lib().og_last_panic().decode())
         return GradeMapMV(_ptr=out.value)
+
+    def packed_root_product(self):
+        """(handle, entries, left_len, right_len, out_len) of the root product's list as 16-byte packed entries on flat rows
+        (cpu-packed variants), or None when the root is not a product of two leaves"""
+        p = C.c_void_p()
+        ll, rl, ol = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        n = lib().og_pack_root_product(self._p, C.byref(p), C.byref(ll), C.byref(rl), C.byref(ol))
+        if not n:
+            return None
+        return p, int(n), int(ll.value), int(rl.value), int(ol.value)
 
     def eval_batch(self, inputs, in_data, batch, out_row_len, mode=EVAL_RELEASE):
         """inputs: list of GradeMapMV bound in the expression; in_data: list of (batch, row) f64

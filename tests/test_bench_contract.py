@@ -75,3 +75,31 @@ def test_pmc_traffic_tool_parses_rocprofv3_counter_csv(tmp_path, monkeypatch):
     assert run.returncode == 0, run.stderr
     ent = json.load(open(scratch / "profiles" / "traffic.json"))["r12:65536"]
     assert ent["bytes"] == (2 * 1001.0 + 500.0) * 1024 and ent["library"] == "rev-x"
+
+
+def test_packed_cpu_baseline_reproduces_the_oracle_bit_for_bit():
+    """BASELINE.md section 2's `cpu-packed-*` variants run the reference's loop (eval.rs:77-83) over 16-byte packed entries on
+    flat rows: same order, same roundings -- so their rows must equal the literal oracle's, bit for bit (1 and 3 threads)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import pyoracle as og
+    n = 5
+    rng = np.random.default_rng(1)
+    L = og.lib()
+    full = list(range(n + 1))
+    val = lambda: og.GradeMapMV({k: rng.uniform(-1, 1, L.og_n_choose_k(n, k)) for k in full})
+    a, b = val(), val()
+    spec = (og.mv(a) * og.mv(b)).specialize(og.as_algebra([1.0, 1.0, -1.0, 1.0, -1.0]))
+    hnd, n_ent, ll, rl, ol = spec.packed_root_product()
+    assert n_ent == 4 ** n and ll == rl == ol == 2 ** n
+    batch = 7
+    la, ra = rng.uniform(-1, 1, (batch, ll)), rng.uniform(-1, 1, (batch, rl))
+    want = spec.eval_batch([a, b], [la, ra], batch, ol)
+    dbl = C.POINTER(C.c_double)
+    for threads in (1, 3):
+        got = np.empty((batch, ol))
+        L.og_packed_eval_batch(hnd, n_ent, la.ctypes.data_as(dbl), ll, ra.ctypes.data_as(dbl), rl, got.ctypes.data_as(dbl), ol, batch, threads)
+        assert np.array_equal(got, want)
+    L.og_packed_free(hnd)
