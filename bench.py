@@ -644,7 +644,7 @@ def main():
     if args.workload == "r12" and rank == 0 and world == 1 and not args.no_configs and not args.batch and not args.flags:
         for name in SIDE_CONFIGS:
             try:
-                side.append(side_config(name, dev, stream, steps=10, warmup=3))
+                side.append(side_config(name, dev, stream, steps=20, warmup=5))
             except Exception as e:      # never at the expense of the headline line
                 side.append({"key": name, "error": f"{type(e).__name__}: {e}"})
 

@@ -243,18 +243,55 @@ __device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t i
         const uint32_t pos = (w >> 16) & 0x7fffu, neg = w & 0x80000000u;
         const T sc = p.pre_row_scale ? p.pre_row_scale[row] : T(1);
         if (p.pre_width > 0 && p.pre_width <= 16) {
-            uint32_t ev[16];
+            // the row's W entries stay in registers for all the items this thread serves; W is a compile-time constant of the
+            // code that runs (a switch over 1 ... 16), so that the 2 W operand reads of a row are issued together and only the
+            // additions form a chain -- with a run-time W every term was a branch, a wait for its own two reads and five
+            // vector instructions (1,460 vector instructions per item and wave at n = 9)
+            auto run = [&](auto wtag) {
+                constexpr int W = decltype(wtag)::value;
+                uint32_t ev[W];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) ev[k] = k < p.pre_width ? p.pre_entries[k * R + row] : 0u;
-            for (int it = g; it < nitems; it += G) {
-                const T* l = scratch + it * per;
-                const T* r = l + ll;
-                T acc = zero;                                      // the fresh cache buffer of eval.rs:21-33
+                for (int k = 0; k < W; ++k) ev[k] = p.pre_entries[k * R + row];
+                for (int it = g; it < nitems; it += G) {
+                    const char* l = reinterpret_cast<const char*>(scratch + it * per);
+                    const char* r = l + size_t(ll) * sizeof(T);
+                    T acc = zero;                                  // the fresh cache buffer of eval.rs:21-33
+                    // eight terms at a time: their sixteen operand reads are in flight together, then the products join the
+                    // chain in the list's order (eval.rs:82); more at once only costs registers (occupancy of the dense kernel)
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < p.pre_width) acc = acc + list_flip<T>(l[ev[k] & 0x7fffu] * r[(ev[k] >> 16) & 0x7fffu], ev[k] & 0x80000000u);   // eval.rs:82
-                if (p.pre_row_scale) acc = acc * sc;
-                images[it * image_stride + pos] = list_flip<T>(acc, neg);
+                    for (int k0 = 0; k0 < W; k0 += 8) {
+                        T prod[8];
+#pragma unroll
+                        for (int k = k0; k < W && k < k0 + 8; ++k) {
+                            const uint32_t e = ev[k];
+                            prod[k - k0] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
+                                                            *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
+                                                        e & 0x80000000u);
+                        }
+#pragma unroll
+                        for (int k = k0; k < W && k < k0 + 8; ++k) acc = acc + prod[k - k0];
+                    }
+                    if (p.pre_row_scale) acc = acc * sc;
+                    images[it * image_stride + pos] = list_flip<T>(acc, neg);
+                }
+            };
+            switch (p.pre_width) {
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 5: run(std::integral_constant<int, 5>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            case 7: run(std::integral_constant<int, 7>{}); break;
+            case 8: run(std::integral_constant<int, 8>{}); break;
+            case 9: run(std::integral_constant<int, 9>{}); break;
+            case 10: run(std::integral_constant<int, 10>{}); break;
+            case 11: run(std::integral_constant<int, 11>{}); break;
+            case 12: run(std::integral_constant<int, 12>{}); break;
+            case 13: run(std::integral_constant<int, 13>{}); break;
+            case 14: run(std::integral_constant<int, 14>{}); break;
+            case 15: run(std::integral_constant<int, 15>{}); break;
+            default: run(std::integral_constant<int, 16>{}); break;
             }
         } else if (p.pre_width > 0) {
             for (int it = g; it < nitems; it += G) {
@@ -1081,7 +1118,7 @@ struct Mfma16x4<float> {
 // rounded to nearest, which leaves every sum -- also an all-zero one: (+0) + (-0) = +0 -- bit for bit what it would be
 // (tests/test_gpu_dense_oracle.py::test_negative_zero_operands_leave_no_trace).
 template <typename T, bool DEGENERATE, int NDIM, int MODE, bool SCALED = false, bool CHAINED = false>
-__global__ __launch_bounds__(64 << (NDIM - 8)) void k_gp_mfma16x4(DenseArgs<T> p) {
+__global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(2))) void k_gp_mfma16x4(DenseArgs<T> p) {   // (at least two waves per SIMD: 256 registers)
     constexpr bool FAST = MODE >= 1;
     static_assert(!((SCALED || CHAINED) && MODE != 0), "a rescaled basis / a chained product runs on the general staging and stores");
     const T* const left_scale = SCALED ? p.left_scale : nullptr;

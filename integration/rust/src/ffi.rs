@@ -108,6 +108,8 @@ extern "C" {
     pub fn gaast_hip_mv_download(m: Mv, grade: c_int, host: *mut c_void, count: i64) -> c_int;
     pub fn gaast_hip_eval(p: Program, inputs: *const Mv, n_inputs: c_int, batch: i64, out: Mv) -> c_int;
     // multi-GPU (one process per GPU): the gather of result rows over RCCL, see include/gaast_hip.h
+    /// which shared object provides the nccl* entry points (NULL = the system's librccl); before the first comm call
+    pub fn gaast_hip_comm_set_library(path: *const std::os::raw::c_char) -> c_int;
     pub fn gaast_hip_comm_unique_id(id_out: *mut c_void) -> c_int;
     pub fn gaast_hip_comm_init(id: *const c_void, rank: c_int, world: c_int) -> c_int;
     pub fn gaast_hip_comm_destroy() -> c_int;

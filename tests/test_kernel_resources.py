@@ -53,12 +53,17 @@ def _find(kernels, prefix):
 
 
 def test_spills_stay_out_of_the_hot_kernels(kernels):
-    """a handful of registers spill in the 1,024-thread n = 12 f64 instantiations for degenerate metrics / a rescaled basis
-    (128 registers per thread); nothing else spills, and never more than a few registers"""
+    """a few registers spill in cold instantiations of the one-item-per-workgroup kernel at its register caps -- the 1,024-thread
+    n = 12 f64 ones (128 registers per thread) for degenerate metrics / a rescaled basis / a chained list, and chained ones at
+    n = 9 ... 11; the plain (false, false) instantiations of non-degenerate metrics never spill, and no other kernel does"""
     bad = {k: v["spill"] for k, v in kernels.items() if v["spill"]}
-    assert all(k.startswith("k_gp_mfma16x4<double, ") and ", 12, " in k and (k.startswith("k_gp_mfma16x4<double, true") or ", true" in k.split("12, ")[1])
-               for k in bad), bad
-    assert all(v <= 16 for v in bad.values()), bad
+    def cold(k):
+        if not k.startswith("k_gp_mfma16x4<"):
+            return False
+        args = [a.strip() for a in k[len("k_gp_mfma16x4<"):-1].split(",")]     # T, DEGENERATE, N, MODE, SCALED, CHAINED
+        return args[1] == "true" or args[4] == "true" or args[5] == "true"
+    assert all(cold(k) for k in bad), bad
+    assert all(v <= 32 for v in bad.values()), bad
 
 
 @pytest.mark.parametrize("prefix,waves", [

@@ -14,11 +14,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HIP_KERNEL = {"r12": "k_gp_mfma32p", "r8": "k_gp_mfma16x4<float>", "cl41": "gaast_jit", "cl41g1": "gaast_jit", "r12s": "k_gp_spinor12s",
-              "r12d": "k_gp_mfma16x4<double>", "r8d": "k_gp_mfma16x4<double>"}
+              "r12d": "k_gp_mfma16x4<double>", "r8d": "k_gp_mfma16x4<double>", "sand9": "k_gp_mfma16x4<double,...,8,0,false,true> (chained)",
+              "sand10": "k_gp_mfma16x4<double,...,9,0,false,true> (chained)", "gp12f32ee": "k_gp_mfma32p<false,11>"}
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     import gaast_amd
@@ -69,7 +70,7 @@ def main():
                 "source": f"profiles/{tag}_{name}_pmc_counters.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 for gfx950)"}
     # entries measured with other kernel sources stay in the file but bench.py reports them as stale
     json.dump(table, open(table_path, "w"), indent=1, sort_keys=True)
-    for name in ("bench_default.json", "bench_rehearsal_2ranks.json", "bench_r8.json", "bench_cl41.json", "sweep_dims.txt"):
+    for name in ("bench_default.json", "bench_rehearsal_2ranks.json", "bench_rehearsal_3ranks.json", "bench_r8.json", "bench_cl41.json", "sweep_dims.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             open(os.path.join(dst, f"{tag}_{name}"), "w").write(open(p).read())

@@ -26,3 +26,5 @@ for k in sorted(vals):
 out.close()
 print(open(f"gpurun_out/pmc_{tag}/summary.csv").read())
 PY
+# the raw per-dispatch CSVs are tens of MiB per pass: gpurun copies at most 64 MiB back, the summary is what is filed
+find gpurun_out/pmc_${tag} -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
