@@ -211,9 +211,9 @@ __device__ __forceinline__ double list_flip<double>(double v, uint32_t sign31) {
     return __hiloint2double(__double2hiint(v) ^ int(sign31), __double2loint(v));
 }
 
+// the list's operand rows of `nitems` items -> scratch (raw, canonicalised like a product operand of eval.rs:27-31)
 template <typename T, int THREADS>
-__device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t item0, int nitems, T* __restrict__ images,
-                                                int image_stride, T* __restrict__ scratch, int tid) {
+__device__ __forceinline__ void list_fill_scratch(const DenseArgs<T>& p, int64_t item0, int nitems, T* __restrict__ scratch, int tid) {
     const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl;
     const T zero = T(0);
     const float inv_per = 1.0f / float(per > 0 ? per : 1);
@@ -230,8 +230,15 @@ __device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t i
         }
         scratch[e] = v;
     }
-    if (THREADS > 64) __syncthreads();
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // a single wave: its own writes, in order
+}
+
+// the rows of the list over the operand rows in scratch -> the operand image (and, neg_off != 0, its negated copy neg_off
+// elements further: the image-pair kernels' register-prefetch path has no separate negation pass)
+template <typename T, int THREADS>
+__device__ __forceinline__ void list_eval_rows(const DenseArgs<T>& p, int nitems, T* __restrict__ images, int image_stride,
+                                               const T* __restrict__ scratch, int tid, int neg_off = 0) {
+    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl;
+    const T zero = T(0);
     const int R = p.pre_rows;
     // rows are dealt to threads; when there are more threads than rows, THREADS / R groups of threads serve different items
     const int G = THREADS >= R ? THREADS / R : 1;
@@ -272,7 +279,11 @@ __device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t i
                         for (int k = k0; k < W && k < k0 + 8; ++k) acc = acc + prod[k - k0];
                     }
                     if (p.pre_row_scale) acc = acc * sc;
-                    images[it * image_stride + pos] = list_flip<T>(acc, neg);
+                    {
+                        const T val = list_flip<T>(acc, neg);
+                        images[it * image_stride + pos] = val;
+                        if (neg_off) images[it * image_stride + pos + neg_off] = -val;
+                    }
                 }
             };
             switch (p.pre_width) {
@@ -303,7 +314,11 @@ __device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t i
                     acc = acc + list_flip<T>(l[e & 0x7fffu] * r[(e >> 16) & 0x7fffu], e & 0x80000000u);
                 }
                 if (p.pre_row_scale) acc = acc * sc;
-                images[it * image_stride + pos] = list_flip<T>(acc, neg);
+                {
+                        const T val = list_flip<T>(acc, neg);
+                        images[it * image_stride + pos] = val;
+                        if (neg_off) images[it * image_stride + pos + neg_off] = -val;
+                    }
             }
         } else {
             const uint32_t e0 = p.pre_row_start[row], e1 = p.pre_row_start[row + 1];
@@ -316,10 +331,23 @@ __device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t i
                     acc = acc + (l[lr & 0xffffu] * r[lr >> 16]) * p.pre_coeff[k];   // eval.rs:82
                 }
                 if (p.pre_row_scale) acc = acc * sc;
-                images[it * image_stride + pos] = list_flip<T>(acc, neg);
+                {
+                        const T val = list_flip<T>(acc, neg);
+                        images[it * image_stride + pos] = val;
+                        if (neg_off) images[it * image_stride + pos + neg_off] = -val;
+                    }
             }
         }
     }
+}
+
+template <typename T, int THREADS>
+__device__ __forceinline__ void stage_from_list(const DenseArgs<T>& p, int64_t item0, int nitems, T* __restrict__ images,
+                                                int image_stride, T* __restrict__ scratch, int tid) {
+    list_fill_scratch<T, THREADS>(p, item0, nitems, scratch, tid);
+    if (THREADS > 64) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // a single wave: its own writes, in order
+    list_eval_rows<T, THREADS>(p, nitems, images, image_stride, scratch, tid);
 }
 
 // result component -> graded row: out_map word = offset | negate << 30 (the blade's reordering sign under the basis
@@ -1120,7 +1148,7 @@ struct Mfma16x4<float> {
 template <typename T, bool DEGENERATE, int NDIM, int MODE, bool SCALED = false, bool CHAINED = false>
 __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_eu(2))) void k_gp_mfma16x4(DenseArgs<T> p) {   // (at least two waves per SIMD: 256 registers)
     constexpr bool FAST = MODE >= 1;
-    static_assert(!((SCALED || CHAINED) && MODE != 0), "a rescaled basis / a chained product runs on the general staging and stores");
+    static_assert(!(SCALED && MODE != 0), "a rescaled basis runs on the general staging and stores");
     const T* const left_scale = SCALED ? p.left_scale : nullptr;
     const T* const right_scale = SCALED ? p.right_scale : nullptr;
     const T* const out_scale = SCALED ? p.out_scale : nullptr;
@@ -1223,25 +1251,39 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
     static_assert((N / CPP) == PPT * THREADS, "four components of each row per thread");
     uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
     T pf_l[4], pf_r[4];
+    // CHAINED with the register-prefetch staging: the left operand is computed from a list over two other rows (stage_from_list).
+    // When the list's LEFT row is the very row the dense product reads as its right operand (R in (R X) ~R) the prefetched
+    // pieces also fill the list's scratch copy; the list's right row (X: n components) rides in one register per thread.
+    const bool same_src = CHAINED && p.pre_left == p.right && p.pre_left_stride == p.right_stride && p.pre_left_len == N &&
+                          p.pre_right_len <= THREADS;
+    T pf_x = T(0);
     auto fetch = [&](int64_t item) {   // (uniform) row base + the thread's pieces
 #pragma unroll
         for (int m = 0; m < PPT; ++m) {
             uint32_t o = uint32_t(tid + m * THREADS) * 16u;   // (uniform row base) + (32-bit lane offset), see the stores
             asm volatile("" : "+v"(o));
-            const uint4 xl = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + o);
+            if constexpr (!CHAINED) {
+                const uint4 xl = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + o);
+                __builtin_memcpy(&pf_l[m * CPP], &xl, 16);
+            }
             const uint4 xr = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.right + item * p.right_stride) + o);
-            __builtin_memcpy(&pf_l[m * CPP], &xl, 16);
             __builtin_memcpy(&pf_r[m * CPP], &xr, 16);
+        }
+        if constexpr (CHAINED) {
+            if (same_src && tid < p.pre_right_len) pf_x = p.pre_right[item * p.pre_right_stride + tid];
         }
     };
     if (FAST) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = ((e / CPP) * THREADS + tid) * CPP + (e % CPP);   // component of the row
-            const uint32_t ml = p.left_map[idx], mr = p.right_map[idx];
-            wa[e] = A_BASE + (((ml >> 16) & 0x7fffu) << ES);
+            const uint32_t mr = p.right_map[idx];
+            if constexpr (!CHAINED) {
+                const uint32_t ml = p.left_map[idx];
+                wa[e] = A_BASE + (((ml >> 16) & 0x7fffu) << ES);
+                sa[e] = ml & 0x80000000u;
+            }
             wb[e] = B_BASE + (((mr >> 16) & 0x7fffu) << ES);
-            sa[e] = ml & 0x80000000u;
             sb[e] = mr & 0x80000000u;
         }
         if (int64_t(blockIdx.x) < p.batch) fetch(blockIdx.x);
@@ -1252,18 +1294,46 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
         if (FAST) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                T yl = pf_l[e], yr = pf_r[e];
-                if (p.left_signs) yl = MM::flip(yl, sa[e]);   // (uniform) folded sign arms / a permuted basis; the B side always
-                yr = MM::flip(yr, sb[e]);                     // carries the b_hi part of (-1)^(|a_hi| |b_lo|)
-                *(lds_t*)(lds + wa[e]) = yl;
-                *(lds_t*)(lds + wa[e] + NEG_A) = -yl;
+                T yr = pf_r[e];
+                if constexpr (CHAINED) {
+                    if (same_src) {   // the list's copy of this row: raw, canonicalised like a product operand (eval.rs:27-31)
+                        const int idx = ((e / CPP) * THREADS + tid) * CPP + (e % CPP);
+                        smem[p.pre_scratch + idx] = p.pre_canon_left ? T(0) + yr : yr;
+                    }
+                } else {
+                    T yl = pf_l[e];
+                    if (p.left_signs) yl = MM::flip(yl, sa[e]);   // (uniform) folded sign arms / a permuted basis; the B side always
+                    *(lds_t*)(lds + wa[e]) = yl;                  // carries the b_hi part of (-1)^(|a_hi| |b_lo|)
+                    *(lds_t*)(lds + wa[e] + NEG_A) = -yl;
+                }
+                yr = MM::flip(yr, sb[e]);
                 *(lds_t*)(lds + wb[e]) = yr;
                 *(lds_t*)(lds + wb[e] + NEG) = -yr;
             }
-            lds_barrier<THREADS>();
+            if constexpr (CHAINED) {
+                if (same_src) {
+                    if (tid < p.pre_right_len) smem[p.pre_scratch + N + tid] = p.pre_canon_right ? T(0) + pf_x : pf_x;
+                } else {
+                    list_fill_scratch<T, THREADS>(p, item, 1, smem + p.pre_scratch, tid);
+                }
+                if (!p.left_full) {   // components no row of the list produces stay zero in both A images
+                    for (int e = tid; e < N; e += THREADS) {
+                        smem[A_EL + e] = T(0);
+                        smem[A_EL + N + PAD_A + e] = T(0);
+                    }
+                }
+                if (THREADS > 64) __syncthreads();
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else {
+                lds_barrier<THREADS>();
+            }
             // in flight during the products below.  Unconditional (the last item re-reads itself): the loop then issues a
             // KNOWN number of loads and stores per item, and the wait at its top is a counted one
             fetch(item + gridDim.x < p.batch ? item + gridDim.x : item);
+            if constexpr (CHAINED) {
+                list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, N + PAD_A);   // +A and -A at once
+                lds_barrier<THREADS>();
+            }
         } else {
             if (!p.left_full || !p.right_full) {
                 for (int e = tid; e < 4 * N + PAD_A; e += THREADS) smem[e] = T(0);

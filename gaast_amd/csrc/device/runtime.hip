@@ -307,7 +307,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
                 }
             };
-            // a rescaled basis (general diagonal metric) / a chained product: general staging and stores only
+            // a rescaled basis (general diagonal metric): general staging and stores only; a chained product: every mode
             const KernD kd = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
                 constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
                 switch (n) {
@@ -318,11 +318,23 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, 0, SC, CH> : &k_gp_mfma16x4<T, false, 12, 0, SC, CH>;
                 }
             });
-            const KernD kf = pick(std::integral_constant<int, 1>{}), kw = pick(std::integral_constant<int, 2>{});
+            auto pick_chained = [&](auto mode_tag) -> KernD {
+                constexpr int F = decltype(mode_tag)::value;
+                switch (n) {
+                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, F, false, true> : &k_gp_mfma16x4<T, false, 8, F, false, true>;
+                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, F, false, true> : &k_gp_mfma16x4<T, false, 9, F, false, true>;
+                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, F, false, true> : &k_gp_mfma16x4<T, false, 10, F, false, true>;
+                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, F, false, true> : &k_gp_mfma16x4<T, false, 11, F, false, true>;
+                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F, false, true> : &k_gp_mfma16x4<T, false, 12, F, false, true>;
+                }
+            };
+            const bool chained_fast = s.chained && !s.scaled;
+            const KernD kf = chained_fast ? pick_chained(std::integral_constant<int, 1>{}) : pick(std::integral_constant<int, 1>{}),
+                        kw = chained_fast ? pick_chained(std::integral_constant<int, 2>{}) : pick(std::integral_constant<int, 2>{});
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
             s.kern[2] = reinterpret_cast<const void*>(kw);
-            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + ((s.scaled || s.chained) ? ",0" + vs + ">" : ",0|1|2>");   // staging / store mode: by alignment at launch
+            s.hip_kernel = "k_gp_mfma16x4<" + tn + "," + dg + "," + std::to_string(n) + (s.scaled ? ",0" + vs + ">" : ",0|1|2" + vs + ">");   // staging / store mode: by alignment at launch
             for (int v = 0; v < 3; ++v)
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
@@ -545,7 +557,10 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.left_scale = s.scaled ? static_cast<const T*>(s.d_coeff) : nullptr;
         p.right_scale = s.scaled ? static_cast<const T*>(s.d_coeff_b) : nullptr;
         p.out_scale = s.scaled ? static_cast<const T*>(s.d_coeff_c) : nullptr;
-        const bool prefetch = s.use_mfma16 && s.kern[1] && p.left_contig && p.right_contig && p.left_full && p.right_full && !s.scaled;
+        // register-prefetch staging: full, contiguous, aligned operand rows; a chained step computes its left operand from a list
+        // (then only the right row is prefetched)
+        const bool prefetch = s.use_mfma16 && s.kern[1] && p.right_contig && p.right_full && !s.scaled &&
+                              (s.chained ? true : (p.left_contig && p.left_full));
         const bool whole_rows = prefetch && s.kern[2] && s.out_full && !s.beta;   // k_gp_mfma16x4: straight-line result stores
         hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[whole_rows ? 2 : prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);
