@@ -1006,7 +1006,12 @@ bool try_fuse(Plan& plan) {
     // in registers and only needs it to be small enough for that -- plans that fit only the latter are fused
     // "JIT only" (the runtime falls back to an unfused plan if the compilation fails)
     // (plans with exp / log steps have no interpreter micro-ops: the specialised kernel or nothing)
-    const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > 48 * 1024) && !plan.has_explog;
+    // (round 3: 144 KiB instead of 48 -- one 512-thread workgroup per CU -- so that programs whose slab is beyond the registers of
+    //  the specialised kernel but whose lists are short still run as ONE launch: the projected sandwich (R X ~R).g(1) at n = 7, 8
+    //  has two lists of n 2^(n-1) entries over a slab of 2^n + 2 n elements; as two list launches it ran 8 active lanes per item)
+    //  -- for plans of SEVERAL steps only: a single big list is better off on k_product_ell (twice the terms per second)
+    const size_t interp_budget = plan.steps.size() >= 2 ? kInterpLdsBytes : size_t(48 * 1024);
+    const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > interp_budget) && !plan.has_explog;
     const int jit_slab_limit = plan.dtype == GAAST_F32 ? 200 : 160;
     const bool jit_allowed = !(plan.flags & GAAST_FLAG_NO_JIT) && slab <= jit_slab_limit;
     if (!interp_ok && !jit_allowed) return false;

@@ -360,6 +360,11 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
     }
+    case Step::FUSED: {
+        if (s.jit_function) return GAAST_OK;
+        const size_t lds = (size_t(s.fused_slab) * FUSED_ITEMS + 8) * sizeof(T);
+        return allow_lds(reinterpret_cast<const void*>(&k_ast_fused<T>), lds);
+    }
     default: return GAAST_OK;
     }
 }
