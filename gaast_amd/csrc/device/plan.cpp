@@ -1474,7 +1474,7 @@ static void uniform_csr_to_ell(Plan& plan) {
         if (s.kind != Step::PRODUCT_CSR || s.u32_b.empty()) continue;
         const size_t n_rows = s.u32_b.size();
         const uint32_t width = s.u32_a[1] - s.u32_a[0];
-        bool uniform = width >= 16;
+        bool uniform = width >= 4;   // (round 3: from 4 terms per row on -- R X has n per row; 16 before: such lists ran on k_product_csr, an entry and a coefficient load per term)
         for (size_t i = 0; uniform && i < n_rows; ++i) uniform = s.u32_a[i + 1] - s.u32_a[i] == width;
         for (size_t e = 0; uniform && e < s.coeff.size(); ++e) uniform = s.coeff[e] == 1.0 || s.coeff[e] == -1.0;
         for (size_t e = 0; uniform && e < s.u32_c.size(); ++e) uniform = !(s.u32_c[e] & 0x80000000u);   // right offset < 2^15

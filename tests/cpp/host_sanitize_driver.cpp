@@ -361,7 +361,7 @@ int main() {
             std::snprintf(what, sizeof what, "sandwich n=%d chained", n);
             lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, 0, what, "<- product_csr");
             std::snprintf(what, sizeof what, "sandwich n=%d two launches", n);
-            lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, GAAST_FLAG_DEBUG_NO_CHAIN, what, "product_csr");
+            lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, GAAST_FLAG_DEBUG_NO_CHAIN, what, "product_ell");   // rows of n entries, +-1: the [term][row] form
         }
     }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
