@@ -22,8 +22,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
-    import gaast_amd
-    rev = gaast_amd.lib().gaast_hip_version().decode()
+    # the revision of the library that ran on the GPU box (collect_profiles.sh records it), not of whatever is built here now
+    rev = open(os.path.join(src, "library_version.txt")).read().strip()
     for d in sorted(glob.glob(os.path.join(src, "stats_*"))):
         name = os.path.basename(d)[len("stats_"):]
         # a repeated collection merges into the same directory: the newest summary is the one bench.json belongs to

@@ -9,6 +9,8 @@ phase=${2:-all}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# the kernel revision of the library that is MEASURED (bench.py reports a PMC traffic figure only for the revision it was taken with)
+python3 -c "import gaast_amd; print(gaast_amd.lib().gaast_hip_version().decode())" > $out/library_version.txt
 stats() { # name, bench args...
   name=$1; shift
   d=$out/stats_$name
