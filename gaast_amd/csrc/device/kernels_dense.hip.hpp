@@ -214,14 +214,17 @@ __device__ __forceinline__ double list_flip<double>(double v, uint32_t sign31) {
 // the list's operand rows of `nitems` items -> scratch (raw, canonicalised like a product operand of eval.rs:27-31)
 template <typename T, int THREADS>
 __device__ __forceinline__ void list_fill_scratch(const DenseArgs<T>& p, int64_t item0, int nitems, T* __restrict__ scratch, int tid) {
-    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl;
+    // per item: the left row, the right row, ONE ZERO (the operand pair of the entries that pad a row to a multiple of 4)
+    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl + 1;
     const T zero = T(0);
-    const float inv_per = 1.0f / float(per > 0 ? per : 1);
+    const float inv_per = 1.0f / float(per);
     for (int e = tid; e < nitems * per; e += THREADS) {
         int it, c;
         split_index(e, per, inv_per, nitems, it, c);
         T v;
-        if (c < ll) {
+        if (c == ll + rl) {
+            v = zero;
+        } else if (c < ll) {
             v = p.pre_left[(item0 + it) * p.pre_left_stride + c];
             if (p.pre_canon_left) v = zero + v;
         } else {
@@ -237,7 +240,7 @@ __device__ __forceinline__ void list_fill_scratch(const DenseArgs<T>& p, int64_t
 template <typename T, int THREADS>
 __device__ __forceinline__ void list_eval_rows(const DenseArgs<T>& p, int nitems, T* __restrict__ images, int image_stride,
                                                const T* __restrict__ scratch, int tid, int neg_off = 0) {
-    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl;
+    const int ll = p.pre_left_len, rl = p.pre_right_len, per = ll + rl + 1;
     const T zero = T(0);
     const int R = p.pre_rows;
     // rows are dealt to threads; when there are more threads than rows, THREADS / R groups of threads serve different items
@@ -249,76 +252,36 @@ __device__ __forceinline__ void list_eval_rows(const DenseArgs<T>& p, int nitems
         const uint32_t w = p.pre_row_map[row];
         const uint32_t pos = (w >> 16) & 0x7fffu, neg = w & 0x80000000u;
         const T sc = p.pre_row_scale ? p.pre_row_scale[row] : T(1);
-        if (p.pre_width > 0 && p.pre_width <= 16) {
-            // the row's W entries stay in registers for all the items this thread serves; W is a compile-time constant of the
-            // code that runs (a switch over 1 ... 16), so that the 2 W operand reads of a row are issued together and only the
-            // additions form a chain -- with a run-time W every term was a branch, a wait for its own two reads and five
-            // vector instructions (1,460 vector instructions per item and wave at n = 9)
-            auto run = [&](auto wtag) {
-                constexpr int W = decltype(wtag)::value;
-                uint32_t ev[W];
-#pragma unroll
-                for (int k = 0; k < W; ++k) ev[k] = p.pre_entries[k * R + row];
-                for (int it = g; it < nitems; it += G) {
-                    const char* l = reinterpret_cast<const char*>(scratch + it * per);
-                    const char* r = l + size_t(ll) * sizeof(T);
-                    T acc = zero;                                  // the fresh cache buffer of eval.rs:21-33
-                    // eight terms at a time: their sixteen operand reads are in flight together, then the products join the
-                    // chain in the list's order (eval.rs:82); more at once only costs registers (occupancy of the dense kernel)
-#pragma unroll
-                    for (int k0 = 0; k0 < W; k0 += 8) {
-                        T prod[8];
-#pragma unroll
-                        for (int k = k0; k < W && k < k0 + 8; ++k) {
-                            const uint32_t e = ev[k];
-                            prod[k - k0] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
-                                                            *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
-                                                        e & 0x80000000u);
-                        }
-#pragma unroll
-                        for (int k = k0; k < W && k < k0 + 8; ++k) acc = acc + prod[k - k0];
-                    }
-                    if (p.pre_row_scale) acc = acc * sc;
-                    {
-                        const T val = list_flip<T>(acc, neg);
-                        images[it * image_stride + pos] = val;
-                        if (neg_off) images[it * image_stride + pos + neg_off] = -val;
-                    }
-                }
-            };
-            switch (p.pre_width) {
-            case 1: run(std::integral_constant<int, 1>{}); break;
-            case 2: run(std::integral_constant<int, 2>{}); break;
-            case 3: run(std::integral_constant<int, 3>{}); break;
-            case 4: run(std::integral_constant<int, 4>{}); break;
-            case 5: run(std::integral_constant<int, 5>{}); break;
-            case 6: run(std::integral_constant<int, 6>{}); break;
-            case 7: run(std::integral_constant<int, 7>{}); break;
-            case 8: run(std::integral_constant<int, 8>{}); break;
-            case 9: run(std::integral_constant<int, 9>{}); break;
-            case 10: run(std::integral_constant<int, 10>{}); break;
-            case 11: run(std::integral_constant<int, 11>{}); break;
-            case 12: run(std::integral_constant<int, 12>{}); break;
-            case 13: run(std::integral_constant<int, 13>{}); break;
-            case 14: run(std::integral_constant<int, 14>{}); break;
-            case 15: run(std::integral_constant<int, 15>{}); break;
-            default: run(std::integral_constant<int, 16>{}); break;
-            }
-        } else if (p.pre_width > 0) {
+        if (p.pre_width > 0) {
+            // pre_width is a multiple of 4 (the host pads a row with entries over the zero pair: acc + (+0.0) leaves every acc
+            // bit for bit, and acc is never -0.0 once it has absorbed a term).  Four terms at a time: their entries (consecutive
+            // words for a wave's rows) and eight operand reads are in flight together, then the products join the chain in the
+            // list's order (eval.rs:82).  [A switch over compile-time widths 1 ... 16, with a row's entries held in registers for
+            // all the items a thread serves, measured 10 % faster on the vector kernel (sand8) and the same elsewhere -- and took
+            // the library's build from 2 to 9 minutes.]
             for (int it = g; it < nitems; it += G) {
-                const T* l = scratch + it * per;
-                const T* r = l + ll;
-                T acc = zero;
-                for (int k = 0; k < p.pre_width; ++k) {
-                    const uint32_t e = p.pre_entries[k * R + row];
-                    acc = acc + list_flip<T>(l[e & 0x7fffu] * r[(e >> 16) & 0x7fffu], e & 0x80000000u);
+                const char* l = reinterpret_cast<const char*>(scratch + it * per);
+                const char* r = l + size_t(ll) * sizeof(T);
+                T acc = zero;                                      // the fresh cache buffer of eval.rs:21-33
+                for (int k0 = 0; k0 < p.pre_width; k0 += 4) {
+                    uint32_t ev[4];
+                    T prod[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ev[k] = p.pre_entries[(k0 + k) * R + row];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        prod[k] = list_flip<T>(*reinterpret_cast<const T*>(l + (ev[k] & 0x7fffu) * uint32_t(sizeof(T))) *
+                                                   *reinterpret_cast<const T*>(r + ((ev[k] >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
+                                               ev[k] & 0x80000000u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = acc + prod[k];
                 }
                 if (p.pre_row_scale) acc = acc * sc;
                 {
-                        const T val = list_flip<T>(acc, neg);
-                        images[it * image_stride + pos] = val;
-                        if (neg_off) images[it * image_stride + pos + neg_off] = -val;
-                    }
+                    const T val = list_flip<T>(acc, neg);
+                    images[it * image_stride + pos] = val;
+                    if (neg_off) images[it * image_stride + pos + neg_off] = -val;
+                }
             }
         } else {
             const uint32_t e0 = p.pre_row_start[row], e1 = p.pre_row_start[row + 1];
@@ -1313,6 +1276,7 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             if constexpr (CHAINED) {
                 if (same_src) {
                     if (tid < p.pre_right_len) smem[p.pre_scratch + N + tid] = p.pre_canon_right ? T(0) + pf_x : pf_x;
+                    if (tid == 0) smem[p.pre_scratch + N + p.pre_right_len] = T(0);   // the zero pair of the padding entries
                 } else {
                     list_fill_scratch<T, THREADS>(p, item, 1, smem + p.pre_scratch, tid);
                 }

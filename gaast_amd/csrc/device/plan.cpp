@@ -1546,7 +1546,7 @@ static void chain_sparse_into_dense(Plan& plan) {
         int ipb = 1;
         if (dn.use_mfma) ipb = n2 <= 10 ? 4 : n2 == 11 ? 2 : 1;
         else if (!dn.use_mfma16) ipb = std::max(256, 1 << (n2 - 4)) >> (n2 - 4);
-        const size_t scratch = size_t(ipb) * size_t(ll + rl) * elem;
+        const size_t scratch = size_t(ipb) * size_t(ll + rl + 1) * elem;
         const size_t images = size_t(ipb) * (size_t(dn.use_mfma && !dn.mfma32_pairs ? 2 : (dn.use_mfma || dn.use_mfma16) ? 4 : 2) << n2) * elem + 256;
         if (scratch > 48 * 1024 || images + scratch > kLdsBytes - 1024 || w.u32_b.size() > 32768) continue;
         // rows of the list -> components of the dense step's left image
@@ -1579,8 +1579,13 @@ static void chain_sparse_into_dense(Plan& plan) {
             for (size_t r = 0; uniform && r < rows; ++r) uniform = row_start[r + 1] - row_start[r] == width;
             for (size_t e = 0; uniform && e < coeff.size(); ++e) uniform = coeff[e] == 1.0 || coeff[e] == -1.0;
             for (size_t e = 0; uniform && e < entries.size(); ++e) uniform = (entries[e] & 0xffffu) < 0x8000u && (entries[e] >> 16) < 0x8000u;
+            uniform = uniform && ll + rl + 1 < 0x8000;
             if (uniform) {
-                std::vector<uint32_t> ell(entries.size());
+                // padded to a multiple of 4 terms with entries over the zero pair the kernel keeps behind the two rows
+                // (left offset ll + rl from the left row, right offset rl from the right row): acc + (+0.0) changes no acc
+                const uint32_t wpad = (width + 3u) & ~3u;
+                const uint32_t zero_entry = uint32_t(ll + rl) | (uint32_t(rl) << 16);
+                std::vector<uint32_t> ell(size_t(wpad) * rows, zero_entry);
                 for (size_t r = 0; r < rows; ++r)
                     for (uint32_t t = 0; t < width; ++t) {
                         const size_t e = size_t(row_start[r]) + t;
@@ -1588,7 +1593,7 @@ static void chain_sparse_into_dense(Plan& plan) {
                     }
                 entries.swap(ell);
                 coeff.clear();
-                dn.pre_width = int(width);
+                dn.pre_width = int(wpad);
             }
         }
         dn.chained = 1;

@@ -176,6 +176,26 @@ int resident_blocks(const void* kern, int threads, size_t lds, int* per_cu) {
 // block size, dynamic LDS, persistent grid.  A step no kernel of this back end can run (operands beyond the LDS
 // budget) makes program_create fail with UNIMPLEMENTED: an eval then either runs every step or none.
 // ------------------------------------------------------------------------------------------
+// k_gp_mfma16x4<T, DEG, n, MODE, SC, CH> by run-time n and degeneracy.  f64 runs n = 8 ... 12 on it, f32 only n = 8, 9 (f32 at
+// n >= 10 is k_gp_mfma32p's): the f32 instantiations for n = 10 ... 12 would be unreachable, so they are not built.
+template <typename T, int MODE, bool SC, bool CH>
+void (*mfma16x4_kernel(int n, bool degenerate))(DenseArgs<T>) {
+    switch (n) {
+    case 8: return degenerate ? &k_gp_mfma16x4<T, true, 8, MODE, SC, CH> : &k_gp_mfma16x4<T, false, 8, MODE, SC, CH>;
+    case 9: return degenerate ? &k_gp_mfma16x4<T, true, 9, MODE, SC, CH> : &k_gp_mfma16x4<T, false, 9, MODE, SC, CH>;
+    default: break;
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        switch (n) {
+        case 10: return degenerate ? &k_gp_mfma16x4<T, true, 10, MODE, SC, CH> : &k_gp_mfma16x4<T, false, 10, MODE, SC, CH>;
+        case 11: return degenerate ? &k_gp_mfma16x4<T, true, 11, MODE, SC, CH> : &k_gp_mfma16x4<T, false, 11, MODE, SC, CH>;
+        case 12: return degenerate ? &k_gp_mfma16x4<T, true, 12, MODE, SC, CH> : &k_gp_mfma16x4<T, false, 12, MODE, SC, CH>;
+        default: break;
+        }
+    }
+    return nullptr;
+}
+
 // picks the (SCALED, CHAINED) instantiation of a dense kernel family: f(std::bool_constant<SC>, std::bool_constant<CH>)
 template <typename F>
 auto pick_variant(bool scaled, bool chained, F&& f) {
@@ -277,11 +297,11 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 s.lds = size_t(s.items_per_block) * size_t(2 << n) * sizeof(float);
                 if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "dense product does not fit in LDS");
                 using KernD = void (*)(DenseArgs<float>);
+                // (k_gp_mfma32 serves n = 14 only -- 16 waves and 128 KiB of LDS per item; n = 10 ... 13 run on k_gp_mfma32p)
+                if (s.threads != 1024) return set_err(GAAST_ERR_UNIMPLEMENTED, "k_gp_mfma32 is built for n = 14 only");
                 const KernD kern = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
                     constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
-                    return s.threads == 256   ? (s.degenerate ? &k_gp_mfma32<true, 256, SC, CH> : &k_gp_mfma32<false, 256, SC, CH>)
-                           : s.threads == 512 ? (s.degenerate ? &k_gp_mfma32<true, 512, SC, CH> : &k_gp_mfma32<false, 512, SC, CH>)
-                                              : (s.degenerate ? &k_gp_mfma32<true, 1024, SC, CH> : &k_gp_mfma32<false, 1024, SC, CH>);   // n = 14: 16 waves, 128 KiB of LDS
+                    return s.degenerate ? &k_gp_mfma32<true, 1024, SC, CH> : &k_gp_mfma32<false, 1024, SC, CH>;
                 });
                 s.kern[0] = reinterpret_cast<const void*>(kern);
                 s.hip_kernel = "k_gp_mfma32<" + dg + "," + std::to_string(s.threads) + vs + ">";
@@ -297,40 +317,16 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             using KernD = void (*)(DenseArgs<T>);
             // [0]: general staging; [1]: register prefetch (full, contiguous, 16-byte aligned rows at launch); [2]: ... and
             // every blade produced, nothing accumulated: straight-line result stores
-            auto pick = [&](auto mode_tag) -> KernD {
-                constexpr int F = decltype(mode_tag)::value;
-                switch (n) {
-                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, F> : &k_gp_mfma16x4<T, false, 8, F>;
-                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, F> : &k_gp_mfma16x4<T, false, 9, F>;
-                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, F> : &k_gp_mfma16x4<T, false, 10, F>;
-                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, F> : &k_gp_mfma16x4<T, false, 11, F>;
-                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F> : &k_gp_mfma16x4<T, false, 12, F>;
-                }
-            };
+            auto pick = [&](auto mode_tag) -> KernD { return mfma16x4_kernel<T, decltype(mode_tag)::value, false, false>(n, s.degenerate != 0); };
             // a rescaled basis (general diagonal metric): general staging and stores only; a chained product: every mode
             const KernD kd = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
-                constexpr bool SC = decltype(sc)::value, CH = decltype(ch)::value;
-                switch (n) {
-                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, 0, SC, CH> : &k_gp_mfma16x4<T, false, 8, 0, SC, CH>;
-                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, 0, SC, CH> : &k_gp_mfma16x4<T, false, 9, 0, SC, CH>;
-                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, 0, SC, CH> : &k_gp_mfma16x4<T, false, 10, 0, SC, CH>;
-                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, 0, SC, CH> : &k_gp_mfma16x4<T, false, 11, 0, SC, CH>;
-                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, 0, SC, CH> : &k_gp_mfma16x4<T, false, 12, 0, SC, CH>;
-                }
+                return mfma16x4_kernel<T, 0, decltype(sc)::value, decltype(ch)::value>(n, s.degenerate != 0);
             });
-            auto pick_chained = [&](auto mode_tag) -> KernD {
-                constexpr int F = decltype(mode_tag)::value;
-                switch (n) {
-                case 8: return s.degenerate ? &k_gp_mfma16x4<T, true, 8, F, false, true> : &k_gp_mfma16x4<T, false, 8, F, false, true>;
-                case 9: return s.degenerate ? &k_gp_mfma16x4<T, true, 9, F, false, true> : &k_gp_mfma16x4<T, false, 9, F, false, true>;
-                case 10: return s.degenerate ? &k_gp_mfma16x4<T, true, 10, F, false, true> : &k_gp_mfma16x4<T, false, 10, F, false, true>;
-                case 11: return s.degenerate ? &k_gp_mfma16x4<T, true, 11, F, false, true> : &k_gp_mfma16x4<T, false, 11, F, false, true>;
-                default: return s.degenerate ? &k_gp_mfma16x4<T, true, 12, F, false, true> : &k_gp_mfma16x4<T, false, 12, F, false, true>;
-                }
-            };
+            auto pick_chained = [&](auto mode_tag) -> KernD { return mfma16x4_kernel<T, decltype(mode_tag)::value, false, true>(n, s.degenerate != 0); };
             const bool chained_fast = s.chained && !s.scaled;
             const KernD kf = chained_fast ? pick_chained(std::integral_constant<int, 1>{}) : pick(std::integral_constant<int, 1>{}),
                         kw = chained_fast ? pick_chained(std::integral_constant<int, 2>{}) : pick(std::integral_constant<int, 2>{});
+            if (!kd || !kf || !kw) return set_err(GAAST_ERR_UNIMPLEMENTED, "no k_gp_mfma16x4 instantiation for this dimension and value type");
             s.kern[0] = reinterpret_cast<const void*>(kd);
             s.kern[1] = reinterpret_cast<const void*>(kf);
             s.kern[2] = reinterpret_cast<const void*>(kw);
@@ -801,7 +797,7 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
             // the list's operand rows of every item a workgroup stages at once, after the kernel's own images
             s.pre_scratch_off = (s.lds + 15) / 16 * 16;
             const size_t items = size_t(s.items_per_block > 0 ? s.items_per_block : 1);
-            s.lds = s.pre_scratch_off + items * size_t(s.pre_left_len + s.pre_right_len) * dtype_size(plan.dtype);
+            s.lds = s.pre_scratch_off + items * size_t(s.pre_left_len + s.pre_right_len + 1) * dtype_size(plan.dtype);   // + the zero pair
             if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "chained product does not fit in LDS (" + s.name + ")");
             for (int v = 0; v < 3; ++v)
                 if (s.kern[v])
