@@ -363,3 +363,68 @@ def test_rotor_sandwich_beyond_the_fused_slab_is_one_launch(n, metric):
         assert np.all(err <= bound), (i, float((err / bound).max()))
     exact, _, spec3 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_EXACT_ORDER)
     assert np.array_equal(exact, want)
+
+
+def _oracle_and_hip(build, alg, rows, batch, dtype=ga.F64, flags=0):
+    want, wmask = oracle_eval_batch(build, alg, {s: r.astype(np.float64) for s, r in rows.items()}, batch)
+    got, mask, spec = hip_eval_batch(build, alg, rows, batch, dtype=dtype, flags=flags)
+    assert mask == wmask
+    return want, got.astype(np.float64), spec
+
+
+@pytest.mark.parametrize("n,dtype,right_grades,kernel", [
+    (9, ga.F64, "even", "k_gp_mfma16x4<double,false,8,"),        # register-prefetch staging, the list reads OTHER rows than the right operand
+    (9, ga.F64, "partial", "k_gp_mfma16x4<double,false,8,"),     # right operand misses a grade: general staging of a chained step
+    (9, ga.F32, "even", "k_gp_mfma16x4<float,false,8,"),
+    (8, ga.F32, "even", "k_gp_dense<float,false,256,"),          # Cl(7): the vector kernel, 32 items per workgroup
+    (11, ga.F32, "even", "k_gp_mfma32p<false,10,false,true>"),   # Cl(10): k_gp_mfma32p's general staging
+])
+def test_chained_products_with_unrelated_operands(n, dtype, right_grades, kernel):
+    """(A x) B with three different inputs: the list's rows are NOT the dense product's right operand (the sandwich's shortcut
+    does not apply), in both value types, on every kernel family a chained step can land on, with full and partial right
+    operands.  One launch, bit-identical to the two-launch plan, within 4 eps sum|terms| of the oracle."""
+    even = EVEN(n)
+    rg = even if right_grades == "even" else [k for k in even if k != 4]
+    build = lambda B: (B.input(0, even, n) * B.input(1, [1], n)) * B.input(2, rg, n)
+    batch = 4 if n < 11 else 2
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(700 + n)
+    rows = {0: rows_of(n, even, batch, rng, npdt), 1: rows_of(n, [1], batch, rng, npdt), 2: rows_of(n, rg, batch, rng, npdt)}
+    want, got, spec = _oracle_and_hip(build, n, rows, batch, dtype)
+    assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and kernel in spec.launches()[0], spec.launches()
+    _, two, spec2 = _oracle_and_hip(build, n, rows, batch, dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
+    assert len(spec2.launches()) == 2 and np.array_equal(got, two)
+    ax, axmask = oracle_eval_batch(lambda B: B.input(0, even, n) * B.input(1, [1], n), n, {0: rows[0].astype(np.float64), 1: rows[1].astype(np.float64)}, batch)
+    odd = [k for k in range(n + 1) if (axmask >> k) & 1]
+    og = [k for k in range(n + 1) if k % 2 == 1]
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+    for i in range(batch):
+        S = abs_terms_bound(n, row_to_bits(n, odd, ax[i]), row_to_bits(n, rg, rows[2][i].astype(np.float64)))
+        # f32: the intermediate A x itself carries f32 roundings (n terms per component) on top of the second product's bound
+        bound = (4 + (n if dtype == ga.F32 else 0)) * eps * bits_to_row(n, og, S) + 1e-300
+        assert np.all(np.abs(got[i] - want[i]) <= bound), (i, float((np.abs(got[i] - want[i]) / bound).max()))
+
+
+def test_parity_pure_products_accumulate_and_project():
+    """a b + c d with four even operands (the second product ADDS into the buffer the first one wrote: beta = 1 in Cl(n - 1)), and
+    (a b).g(2) + (a b).g(4)-style projections of a parity-pure product (a partial result map: general stores)"""
+    n, batch = 9, 4
+    even = EVEN(n)
+    rng = np.random.default_rng(808)
+    rows = {s: rows_of(n, even, batch, rng) for s in range(4)}
+    build = lambda B: B.input(0, even, n) * B.input(1, even, n) + B.input(2, even, n) * B.input(3, even, n)
+    want, got, spec = _oracle_and_hip(build, n, rows, batch)
+    assert sum("even x even in Cl(8)" in l for l in spec.launches()) == 2, spec.launches()
+    for i in range(batch):
+        S = sum(abs_terms_bound(n, row_to_bits(n, even, rows[a][i]), row_to_bits(n, even, rows[b][i])) for a, b in ((0, 1), (2, 3)))
+        bound = 5 * 2.0 ** -52 * bits_to_row(n, even, S) + 1e-300       # 4 eps per product, one more rounding for the sum
+        assert np.all(np.abs(got[i] - want[i]) <= bound)
+    build2 = lambda B: (B.input(0, even, n) * B.input(1, even, n)).g(2)
+    rows2 = {0: rows[0], 1: rows[1]}
+    want, got, spec = _oracle_and_hip(build2, n, rows2, batch)
+    if any("product_dense" in l for l in spec.launches()):     # (the projection shrinks the list: the planner may keep it on a list kernel)
+        for i in range(batch):
+            S = abs_terms_bound(n, row_to_bits(n, even, rows[0][i]), row_to_bits(n, even, rows[1][i]))
+            assert np.all(np.abs(got[i] - want[i]) <= 4 * 2.0 ** -52 * bits_to_row(n, [2], S) + 1e-300)
+    else:
+        assert np.array_equal(got, want)
