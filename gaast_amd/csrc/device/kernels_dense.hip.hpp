@@ -1436,4 +1436,299 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_gp_mfma7<T>: the n = 7 product (R^7-sized algebras; the Cl(7) products of parity-pure n = 8 operands: rotor composition
+// and the second product of a sandwich in an 8-dimensional algebra) on the 16x16x4 matrix instructions, ONE WAVE PER ITEM,
+// 16 instructions per item -- 4^7 multiply-adds, none wasted.  128 = 16 x 8 components do not fill the 16 x 16 result tile
+// of an instruction as (c_lo, c_hi) does from n = 8 on; here the TOP basis vector is split over the two sides of the tile:
+//     blade = (top, hi3, lo3);   tile row = (u, x): u = top bit of A's blade, x = c_lo;   tile column = (v, y): v = top bit
+//     of B's blade, y = c_hi3;   step = a_hi3 (8 steps), instruction s of a step: b_lo = k_of(kq, s) (2 instructions),
+// so element (u, x | v, y) of the tile is the partial sum of component c = (u ^ v, y, x) over the terms whose A blade has
+// top bit u: every component is the sum of TWO tile elements -- (0, v) and (1, v ^ 1) -- which meet at the end through one
+// lane exchange per result.  Signs are addresses as in the other image-pair kernels (+A, -A, +B, -B in LDS):
+//     A operand (row, k, step):    R(a_lo, b_lo) + |a_lo & b_lo & NEG_lo| + u (|b_lo| + |a_hi3|)
+//     B operand (k, column, step): |y| |b_lo| + R(a_hi3, b_hi3) + |a_hi3 & b_hi3 & NEG_hi3|    (the |b_hi3| |b_lo| part of
+//                                  (-1)^(|a_hi3| |b_lo|) is folded into the B image by the host, as for k_gp_mfma16x4)
+//     result (row, column):        u |y| + u v [top squares to -1];   u v [top is null]: the element contributes nothing
+// (R = parity of the reorderings; a lane's two b_lo have one parity, so that both B words of a step come from one image:
+// one ds_read_b64 (f32) / ds_read_b128 (f64) per step).  A null hi3 vector makes a B read a read of the zero words.
+// LDS (elements): +B [0, 128), -B [128, 256) in the order [kq][v][b_hi3][s]: the 32 lanes that share an LDS cycle read 32
+// consecutive pairs; +A at 256: u * 72 + a_hi3 * 8 + a_lo, -A 144 further: for a step's reads the four (u, sign)
+// combinations are four different groups of eight banks, whatever the lanes' a_lo and signs are; 16 zeros at 544.
+// MODE as in k_gp_mfma16x4: 0 general staging, 1 register prefetch of full rows (a lane moves two components of each row,
+// one per load, dealt by LDS bank on the host), 2 ... and straight-line result stores.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr int mfma7_k(int kq, int s) {
+    constexpr int tab[4][2] = {{0, 3}, {5, 6}, {1, 2}, {4, 7}};
+    return tab[kq][s];
+}
+
+template <typename T, int MODE, bool SCALED = false, bool CHAINED = false>
+__global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
+    constexpr bool FAST = MODE >= 1;
+    static_assert(!(SCALED && MODE != 0), "a rescaled basis runs on the general staging and stores");
+    const T* const left_scale = SCALED ? p.left_scale : nullptr;
+    const T* const right_scale = SCALED ? p.right_scale : nullptr;
+    const T* const out_scale = SCALED ? p.out_scale : nullptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    lds_u8* lds = (lds_u8*)smem_raw;
+    typedef __attribute__((address_space(3))) T lds_t;
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    typedef Mfma16x4<T> MM;
+    constexpr int ES = MM::SHIFT;
+    constexpr int N = 128, THREADS = 64;
+    constexpr int A_EL = 256, NEG_A_EL = 144, ZERO_EL = 544, item_stride = 560;
+    constexpr uint32_t NEG = 128u << ES, NEG_A = uint32_t(NEG_A_EL) << ES, A_BASE = uint32_t(A_EL) << ES, ZERO_BASE = uint32_t(ZERO_EL) << ES;
+    const int tid = threadIdx.x;
+    if (tid < 16) smem[ZERO_EL + tid] = T(0);
+
+    const int i = tid & 15, kq = tid >> 4;
+    const int hi = i >> 3, lo3 = i & 7;   // A operand: tile row (u = hi, x = lo3); B operand and results: tile column (v = hi, y = lo3)
+    const uint32_t neg_hi3 = p.neg_hi & 7u, zero_hi3 = p.zero_hi & 7u, neg_top = (p.neg_hi >> 3) & 1u, zero_top = (p.zero_hi >> 3) & 1u;
+
+    uint32_t aa[2][2];   // A operand of instruction s, by the parity of |a_hi3|; the step adds a_hi3 * 8 elements
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = mfma7_k(kq, s);
+        const int al = lo3 ^ k;
+        const uint32_t par = uint32_t(lo_reorder_parity(al, k) ^ (__builtin_popcount(uint32_t(al & k) & p.neg_lo) & 1) ^ (hi & __builtin_popcount(k) & 1));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) aa[s][q] = A_BASE + (uint32_t(hi * 72 + al) << ES) + ((par ^ uint32_t(hi & q)) ? NEG_A : 0u);
+    }
+    uint32_t ab[8];      // the lane's pair of B words of step a_hi3 (the zero words when the contribution vanishes)
+    {
+        const uint32_t kpar = uint32_t(__builtin_popcount(mfma7_k(kq, 0)) & 1);
+#pragma unroll
+        for (int ah = 0; ah < 8; ++ah) {
+            const int bh = lo3 ^ ah;
+            const uint32_t sg = ((uint32_t(__builtin_popcount(lo3)) & kpar) ^ uint32_t(lo_reorder_parity(ah, bh)) ^
+                                 uint32_t(__builtin_popcount(uint32_t(ah & bh) & neg_hi3))) & 1u;
+            ab[ah] = (uint32_t(kq * 16 + hi * 8 + bh) << (ES + 1)) + (sg ? NEG : 0u);
+            if (uint32_t(ah & bh) & zero_hi3) ab[ah] = ZERO_BASE;   // (a null vector costs nothing per item: no DEGENERATE instantiations)
+        }
+    }
+    // results: each component c = (u ^ v, y, x) is the sum of a tile element this lane keeps and one its partner sends
+    //   f32: a lane's four registers are rows x = 4 (kq & 1) + r of ONE u = kq >> 1; partner = (v ^ 1, kq ^ 2): lane ^ 40;
+    //        the u = 0 lane finishes r = 0, 1, the u = 1 lane r = 2, 3
+    //   f64: register r is row 4 r + kq: u = r >> 1, x = 4 (r & 1) + kq; partner = (v ^ 1): lane ^ 8; every lane finishes
+    //        its u = 0 registers
+    constexpr bool F32 = sizeof(T) == 4;
+    const int u_lane = F32 ? (kq >> 1) : 0;
+    const int partner_addr = (tid ^ (F32 ? 40 : 8)) << 2;
+    // sign / vanishing of the u = 1 tile elements of this lane (u = 0 elements carry neither)
+    const uint32_t u1_sign = ((uint32_t(__builtin_popcount(lo3)) ^ (uint32_t(hi) & neg_top)) & 1u) << 31;
+    const uint32_t u1_mask = (uint32_t(hi) & zero_top) ? 0u : ~0u;
+    uint32_t ooff[2], osg[2];
+    bool ook[2];
+    T osc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = F32 ? 4 * (kq & 1) + (u_lane ? 2 + j : j) : 4 * j + kq;
+        const int c = ((u_lane ^ hi) << 6) | (lo3 << 3) | x;
+        const int32_t w = p.out_map[c];
+        ook[j] = w >= 0;
+        ooff[j] = uint32_t(w & 0x3fffffff) << ES;
+        osg[j] = (uint32_t(w) & 0x40000000u) << 1;
+        osc[j] = (SCALED && out_scale) ? out_scale[c] : T(1);
+    }
+
+    // FAST: every blade of both operands is loaded (the host checks): entry q = load * 64 + lane of a map is this lane's
+    // component of load `load` -- row offset, image address, negate bit -- dealt by the host so that the lanes sharing an
+    // LDS cycle store to different banks (plan.cpp: build_map); the rows need no alignment
+    uint32_t wa[2] = {0, 0}, wb[2] = {0, 0}, sa[2] = {0, 0}, sb[2] = {0, 0}, oa[2] = {0, 0}, ob[2] = {0, 0};
+    // TWO items are in flight per wave (register sets 0 / 1, the item loop is unrolled by two): with one, the 32 waves of a CU
+    // keep 32 KiB of loads in flight (f32) -- measured 3.6 TB/s; an HBM access under load takes the time of ~2 items
+    struct Pf {
+        T l[2], r[2], x;
+    } pf[2];
+    pf[0].x = pf[1].x = T(0);
+    const bool same_src = CHAINED && p.pre_left == p.right && p.pre_left_stride == p.right_stride && p.pre_left_len == N &&
+                          p.pre_right_len <= THREADS;
+    auto fetch = [&](int64_t item, Pf& f) {   // (uniform) row base + the lane's byte offsets
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if constexpr (!CHAINED) {
+                uint32_t o = oa[e];
+                asm volatile("" : "+v"(o));
+                f.l[e] = *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + o);
+            }
+            uint32_t o = ob[e];
+            asm volatile("" : "+v"(o));
+            f.r[e] = *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.right + item * p.right_stride) + o);
+        }
+        if constexpr (CHAINED) {
+            if (same_src && tid < p.pre_right_len) f.x = p.pre_right[item * p.pre_right_stride + tid];
+        }
+    };
+    if (FAST) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int q = e * THREADS + tid;
+            const uint32_t mr = p.right_map[q];
+            if constexpr (!CHAINED) {
+                const uint32_t ml = p.left_map[q];
+                oa[e] = (ml & 0xffffu) << ES;
+                wa[e] = A_BASE + (((ml >> 16) & 0x7fffu) << ES);
+                sa[e] = ml & 0x80000000u;
+            }
+            ob[e] = (mr & 0xffffu) << ES;
+            wb[e] = ((mr >> 16) & 0x7fffu) << ES;
+            sb[e] = mr & 0x80000000u;
+        }
+        if (int64_t(blockIdx.x) < p.batch) {
+            fetch(blockIdx.x, pf[0]);
+            fetch(int64_t(blockIdx.x) + gridDim.x < p.batch ? int64_t(blockIdx.x) + gridDim.x : int64_t(blockIdx.x), pf[1]);
+        }
+    }
+
+    auto one_item = [&](int64_t item, Pf& f) {
+        // ---- both operands into their +/- images ----
+        if (FAST) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                T yr = f.r[e];
+                if constexpr (CHAINED) {
+                    if (same_src) smem[p.pre_scratch + (ob[e] >> ES)] = p.pre_canon_left ? T(0) + yr : yr;   // the list's copy of this row
+                } else {
+                    T yl = f.l[e];
+                    if (p.left_signs) yl = MM::flip(yl, sa[e]);
+                    *(lds_t*)(lds + wa[e]) = yl;
+                    *(lds_t*)(lds + wa[e] + NEG_A) = -yl;
+                }
+                yr = MM::flip(yr, sb[e]);
+                *(lds_t*)(lds + wb[e]) = yr;
+                *(lds_t*)(lds + wb[e] + NEG) = -yr;
+            }
+            if constexpr (CHAINED) {
+                if (same_src) {
+                    if (tid < p.pre_right_len) smem[p.pre_scratch + N + tid] = p.pre_canon_right ? T(0) + f.x : f.x;
+                    if (tid == 0) smem[p.pre_scratch + N + p.pre_right_len] = T(0);   // the zero pair of the padding entries
+                } else {
+                    list_fill_scratch<T, THREADS>(p, item, 1, smem + p.pre_scratch, tid);
+                }
+                if (!p.left_full) {   // components no row of the list produces stay zero in both A images
+                    for (int e = tid; e < 2 * NEG_A_EL; e += THREADS) smem[A_EL + e] = T(0);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else {
+                lds_barrier<THREADS>();
+            }
+            {   // the item after the next one, into the registers just consumed; unconditional (the last items re-read themselves):
+                // a known number of loads per item
+                const int64_t nn = item + 2 * int64_t(gridDim.x);
+                fetch(nn < p.batch ? nn : item, f);
+            }
+            if constexpr (CHAINED) {
+                list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, NEG_A_EL);   // +A and -A at once
+                lds_barrier<THREADS>();
+            }
+        } else {
+            if (!p.left_full || !p.right_full) {
+                for (int e = tid; e < ZERO_EL; e += THREADS) smem[e] = T(0);
+                lds_barrier<THREADS>();
+            }
+            if constexpr (CHAINED)
+                stage_from_list<T, THREADS>(p, item, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid);
+            else
+                stage_operands<T, THREADS>(p.left + item * p.left_stride, p.left_stride, p.left_map, p.left_count, p.left_contig,
+                                           p.canon_left, smem + A_EL, item_stride, 1, tid, left_scale);
+            stage_operands<T, THREADS>(p.right + item * p.right_stride, p.right_stride, p.right_map, p.right_count,
+                                       p.right_contig, p.canon_right, smem, item_stride, 1, tid, right_scale);
+            lds_barrier<THREADS>();
+            for (int e = tid; e < N + NEG_A_EL; e += THREADS) {   // the negated images
+                if (e < N) smem[N + e] = -smem[e];
+                else smem[A_EL + NEG_A_EL + (e - N)] = -smem[A_EL + (e - N)];
+            }
+            lds_barrier<THREADS>();
+        }
+
+        typename MM::acc_t acc = {T(0), T(0), T(0), T(0)};
+        // eight steps, software-pipelined like k_gp_mfma16x4's: the operands of step a_hi3 + 1 are requested before the
+        // two MFMAs of step a_hi3 are issued
+        auto load_ops = [&](int ah, T (&av)[2], T (&bv)[2]) {
+            const vec2 q = *(const __attribute__((address_space(3))) vec2*)(lds + ab[ah]);
+            bv[0] = q[0];
+            bv[1] = q[1];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) av[s] = *(const lds_t*)(lds + aa[s][__builtin_popcount(ah) & 1] + (uint32_t(ah * 8) << ES));
+        };
+        T av[2][2], bv[2][2];
+        load_ops(0, av[0], bv[0]);
+#pragma unroll
+        for (int ah = 0; ah < 8; ++ah) {
+            if (ah + 1 < 8) load_ops(ah + 1, av[(ah + 1) & 1], bv[(ah + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = MM::mma(av[ah & 1][s], bv[ah & 1][s], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- the two halves of every component meet ----
+        T keep[2], send[2];
+        auto u1_element = [&](T v) -> T {   // sign and vanishing of a u = 1 tile element, as bit operations
+            if constexpr (F32) {
+                return __uint_as_float((__float_as_uint(float(v)) ^ u1_sign) & u1_mask);
+            } else {
+                return T(__hiloint2double(int((uint32_t(__double2hiint(double(v))) ^ u1_sign) & u1_mask), int(uint32_t(__double2loint(double(v))) & u1_mask)));
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (F32) {   // u = 1 lanes send r = 0, 1 and finish r = 2, 3
+                send[j] = u_lane ? u1_element(acc[j]) : acc[2 + j];
+                keep[j] = u_lane ? u1_element(acc[2 + j]) : acc[j];
+            } else {
+                send[j] = u1_element(acc[2 + j]);
+                keep[j] = acc[j];
+            }
+        }
+        T res[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            T got;
+            if constexpr (F32) {
+                got = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(float(send[j]))));
+            } else {
+                const int lo_w = __builtin_amdgcn_ds_bpermute(partner_addr, __double2loint(double(send[j])));
+                const int hi_w = __builtin_amdgcn_ds_bpermute(partner_addr, __double2hiint(double(send[j])));
+                got = T(__hiloint2double(hi_w, lo_w));
+            }
+            res[j] = keep[j] + got;
+        }
+
+        // ---- results -> graded row ----
+        unsigned char* orow = reinterpret_cast<unsigned char*>(p.out + item * p.out_stride);
+        if constexpr (MODE == 2) {
+            if (p.out_signs) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) res[j] = T(0) + MM::flip(res[j], osg[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t o = ooff[j];
+                asm volatile("" : "+v"(o));
+                *reinterpret_cast<T*>(orow + o) = res[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (ook[j]) {
+                    T* q = reinterpret_cast<T*>(orow + ooff[j]);
+                    T v = res[j];
+                    if (SCALED) v = v * osc[j];
+                    v = MM::flip(v, osg[j]);
+                    if (osg[j] && !p.beta) v = T(0) + v;
+                    *q = p.beta ? *q + v : v;
+                }
+            }
+        }
+        lds_barrier<THREADS>();   // the images are rewritten by the next item
+    };
+    for (int64_t item = blockIdx.x; item < p.batch; item += 2 * int64_t(gridDim.x)) {
+        one_item(item, pf[0]);
+        if (item + gridDim.x < p.batch) one_item(item + gridDim.x, pf[1]);
+    }
+}
+
 }  // namespace gaast

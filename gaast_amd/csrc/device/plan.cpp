@@ -486,7 +486,7 @@ struct Lowering {
         return true;
     }
 
-    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>), in which algebra
+    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>, 5 = k_gp_mfma7<T>), in which algebra
     // (frame) and in which basis of it (perm)
     int dense_kind_for(const DenseFrame& f, uint64_t n_comp_muls, std::vector<int>& perm) const {
         const int n = f.n;
@@ -504,6 +504,8 @@ struct Lowering {
         if (plan.dtype == GAAST_F64 && !(plan.flags & GAAST_FLAG_NO_MFMA) && n >= 8 && n <= 12 &&
             dense_basis_permutation(f, 4, false, perm))
             return 4;
+        // n = 7, both value types: one wave per item on the 16x16x4 instructions (lo = 3 bits: three non-null vectors)
+        if (n == 7 && !(plan.flags & GAAST_FLAG_NO_MFMA) && dense_basis_permutation(f, 3, false, perm)) return 5;
         if (dense_basis_permutation(f, 4, true, perm)) return 1;
         return 0;
     }
@@ -685,6 +687,7 @@ struct Lowering {
             s.use_mfma = dense_kind == 3;
             s.use_mfma16 = dense_kind == 4;
             s.use_mfma16d = dense_kind == 4;
+            s.use_mfma7 = dense_kind == 5;
             s.mfma16_quads = dense_kind == 4 && plan.dtype == GAAST_F32;   // k_gp_mfma16x4<float>: B words in 16-byte quads
             s.mfma32_pairs = dense_kind == 3 && n2 <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
             // blade R of the frame's basis <-> blade R' of its permuted basis, f_R = sign(R) f'_R' (the parity of the
@@ -774,6 +777,14 @@ struct Lowering {
                 const uint32_t x = m >> 4, k = m & 15u;
                 return (x << 4) | (uint32_t(kq_of[k] ^ int(((x >> 2) & 1u) << 1)) << 2) | uint32_t(s_of[k]);
             };
+            // k_gp_mfma7: A image u * 72 + (a_hi3, a_lo); B image [kq][v][b_hi3][s] with (kq, s) from the kernel's k table (mfma7_k)
+            auto mfma7_a_pos = [](uint32_t m) { return (m & 63u) + (m >> 6) * 72u; };
+            auto mfma7_b_pos = [](uint32_t m) {
+                static const int kq_of[8] = {0, 2, 2, 0, 3, 1, 1, 3};
+                static const int s_of[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+                const uint32_t v = m >> 6, bh = (m >> 3) & 7u, k = m & 7u;
+                return ((uint32_t(kq_of[k]) * 16u + v * 8u + bh) << 1) | uint32_t(s_of[k]);
+            };
             auto mfma_b_pos = [](uint32_t m) {
                 const uint32_t x = m >> 5, k = m & 31;
                 const uint32_t lq = ((k & 1) << 2) | (k >> 3);
@@ -795,8 +806,10 @@ struct Lowering {
                         // image-pair kernels: the b_hi part of (-1)^(|a_hi| |b_lo|), |a_hi| = |b_hi| + |c_hi| (mod 2), lives in the B image
                         if (s.use_mfma16 && right) neg ^= uint32_t(__builtin_popcount(blade >> 4) & __builtin_popcount(blade & 15u) & 1);
                         if (s.mfma32_pairs && right) neg ^= uint32_t(__builtin_popcount(blade >> 5) & __builtin_popcount(blade & 31u) & 1);
+                        if (s.use_mfma7 && right) neg ^= uint32_t(__builtin_popcount((blade >> 3) & 7u) & __builtin_popcount(blade & 7u) & 1);
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
-                        const uint32_t pos = s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
+                        const uint32_t pos = s.use_mfma7 ? (right ? mfma7_b_pos(blade) : mfma7_a_pos(blade))
+                                             : s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
                                              : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
                                              : s.mfma16_quads ? (right ? mfma16q_b_pos(blade) : blade)
                                              : s.use_mfma16d ? (right ? mfma16d_b_pos(blade) : blade) : vec_pos(blade);
@@ -808,6 +821,30 @@ struct Lowering {
                 }
                 *full = map.size() == (size_t(1) << n2);
                 *contig = seq && map.size() % 4 == 0 && !map.empty();
+                if (s.use_mfma7 && *full) {
+                    // k_gp_mfma7 moves ONE component per lane and load (entry q = load * 64 + lane), so the entries can be dealt
+                    // to lanes by LDS bank: the lanes that share an LDS cycle of a store (f32: 32 lanes, bank = position mod 32;
+                    // f64: 16 lanes of 8 bytes, position mod 16) get components of different banks -- every residue holds
+                    // 128 / G positions of an image, one per run of G entries.  (Row order put 36 conflict cycles into the
+                    // ~108 LDS cycles an item cost.)  The row offsets are no longer 0, 1, 2, ...: no 16-byte vector path.
+                    const uint32_t G = plan.dtype == GAAST_F32 ? 32u : 16u;
+                    std::vector<std::vector<size_t>> bucket(G);
+                    for (size_t e = 0; e < map.size(); ++e) bucket[((map[e] >> 16) & 0x7fffu) % G].push_back(e);
+                    bool even = true;
+                    for (const auto& b : bucket) even = even && b.size() == map.size() / G;
+                    if (even) {
+                        std::vector<uint32_t> m2;
+                        std::vector<double> s2;
+                        for (size_t r = 0; r < map.size() / G; ++r)
+                            for (uint32_t k = 0; k < G; ++k) {
+                                m2.push_back(map[bucket[k][r]]);
+                                s2.push_back(scale[bucket[k][r]]);
+                            }
+                        map.swap(m2);
+                        scale.swap(s2);
+                        *contig = 0;
+                    }
+                }
             };
             uint64_t lwant = lmin & ll.mask, rwant = rmin & lrr.mask;
             build_map(ll, lwant, flip_l, false, s.u32_a, s.coeff, &s.left_full, &s.left_contig);
@@ -839,7 +876,7 @@ struct Lowering {
             for (uint32_t m = 0; m < (1u << n2); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
             for (uint32_t w : s.u32_a) s.left_signs |= int(w >> 31);
             for (int32_t w : s.i32_a) s.out_signs |= int(w >= 0 && (uint32_t(w) & 0x40000000u));
-            const int lo_bits = s.use_mfma ? 5 : 4;
+            const int lo_bits = s.use_mfma ? 5 : s.use_mfma7 ? 3 : 4;
             for (int j = 0; j < n2; ++j) {
                 const double g = frame.metric[size_t(perm[size_t(j)])];   // only its sign matters here: the magnitude is in the scales
                 if (j < lo_bits) {
@@ -1545,9 +1582,9 @@ static void chain_sparse_into_dense(Plan& plan) {
         // items a workgroup of the dense kernel stages at once (runtime.hip: prepare_step)
         int ipb = 1;
         if (dn.use_mfma) ipb = n2 <= 10 ? 4 : n2 == 11 ? 2 : 1;
-        else if (!dn.use_mfma16) ipb = std::max(256, 1 << (n2 - 4)) >> (n2 - 4);
+        else if (!dn.use_mfma16 && !dn.use_mfma7) ipb = std::max(256, 1 << (n2 - 4)) >> (n2 - 4);
         const size_t scratch = size_t(ipb) * size_t(ll + rl + 1) * elem;
-        const size_t images = size_t(ipb) * (size_t(dn.use_mfma && !dn.mfma32_pairs ? 2 : (dn.use_mfma || dn.use_mfma16) ? 4 : 2) << n2) * elem + 256;
+        const size_t images = size_t(ipb) * (size_t(dn.use_mfma && !dn.mfma32_pairs ? 2 : (dn.use_mfma || dn.use_mfma16 || dn.use_mfma7) ? 4 : 2) << n2) * elem + 256;
         if (scratch > 48 * 1024 || images + scratch > kLdsBytes - 1024 || w.u32_b.size() > 32768) continue;
         // rows of the list -> components of the dense step's left image
         std::vector<int32_t> map_of(size_t(row_len(buf)), -1);

@@ -97,6 +97,7 @@ struct Step {
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)
+    int use_mfma7 = 0;   // k_gp_mfma7<T> (n = 7: lo = 3 bits, the top vector split over the two sides of the 16 x 16 tile)
     int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout
     int mfma32_pairs = 0;  // k_gp_mfma32p (image-pair form, f32, n = 10 ... 13) instead of k_gp_mfma32
     int spinor_lam_bit = -1, spinor_has_alpha = 0;  // index basis of the matrix-representation kernels: spinor_basis.hpp

@@ -335,6 +335,24 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
         }
+        if (s.use_mfma7) {
+            // k_gp_mfma7<T>: one wave per item, single-wave workgroups
+            s.threads = 64;
+            s.items_per_block = 1;
+            s.lds = size_t(560) * sizeof(T);   // +B, -B, +A (u = 1 half 72 further), -A 144 further, 16 zeros
+            using KernD = void (*)(DenseArgs<T>);
+            const KernD kd = pick_variant(s.scaled, s.chained, [&](auto sc, auto ch) -> KernD {
+                return &k_gp_mfma7<T, 0, decltype(sc)::value, decltype(ch)::value>;
+            });
+            const bool chained_fast = s.chained && !s.scaled;
+            const KernD kf = chained_fast ? &k_gp_mfma7<T, 1, false, true> : &k_gp_mfma7<T, 1>;
+            const KernD kw = chained_fast ? &k_gp_mfma7<T, 2, false, true> : &k_gp_mfma7<T, 2>;
+            s.kern[0] = reinterpret_cast<const void*>(kd);
+            s.kern[1] = reinterpret_cast<const void*>(kf);
+            s.kern[2] = reinterpret_cast<const void*>(kw);
+            s.hip_kernel = "k_gp_mfma7<" + tn + (s.scaled ? ",0" + vs + ">" : ",0|1|2" + vs + ">");   // (null vectors: run-time, no instantiation of their own)
+            return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent single-wave workgroups
+        }
         const int lpi = 1 << (n - 4);
         s.threads = lpi > 256 ? lpi : 256;
         s.items_per_block = s.threads / lpi;
@@ -560,8 +578,9 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.out_scale = s.scaled ? static_cast<const T*>(s.d_coeff_c) : nullptr;
         // register-prefetch staging: full, contiguous, aligned operand rows; a chained step computes its left operand from a list
         // (then only the right row is prefetched)
-        const bool prefetch = s.use_mfma16 && s.kern[1] && p.right_contig && p.right_full && !s.scaled &&
-                              (s.chained ? true : (p.left_contig && p.left_full));
+        const bool prefetch = s.use_mfma7 ? (s.kern[1] && p.right_full && !s.scaled && (s.chained || p.left_full))   // one component per lane and load: no alignment needed
+                                          : (s.use_mfma16 && s.kern[1] && p.right_contig && p.right_full && !s.scaled &&
+                                             (s.chained ? true : (p.left_contig && p.left_full)));
         const bool whole_rows = prefetch && s.kern[2] && s.out_full && !s.beta;   // k_gp_mfma16x4: straight-line result stores
         hipLaunchKernelGGL(reinterpret_cast<KernD>(const_cast<void*>(s.kern[whole_rows ? 2 : prefetch ? 1 : 0])), dim3(unsigned(blocks)),
                            dim3(unsigned(s.threads)), s.lds, g_stream, p);

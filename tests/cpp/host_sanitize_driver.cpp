@@ -106,6 +106,15 @@ static uint32_t mfma16q_b_pos(uint32_t m) {
     return (x << 4) | (uint32_t(kq_of[k] ^ int(((x >> 2) & 1u) << 1)) << 2) | uint32_t(s_of[k]);
 }
 
+// k_gp_mfma7's images (plan.cpp: mfma7_a_pos / mfma7_b_pos)
+static uint32_t mfma7_a_pos(uint32_t m) { return (m & 63u) + (m >> 6) * 72u; }
+static uint32_t mfma7_b_pos(uint32_t m) {
+    static const int kq_of[8] = {0, 2, 2, 0, 3, 1, 1, 3};
+    static const int s_of[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+    const uint32_t v = m >> 6, bh = (m >> 3) & 7u, k = m & 7u;
+    return ((uint32_t(kq_of[k]) * 16u + v * 8u + bh) << 1) | uint32_t(s_of[k]);
+}
+
 static void dense_tables_agree_with_the_list(int n, const double* metric, int dtype, uint32_t flags, const char* what,
                                              const char* expect_step, uint64_t lmask = 0, uint64_t rmask = 0) {
     if (!lmask) lmask = full_mask(n);
@@ -132,7 +141,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     // the kernel's algebra: the program's, or Cl(n - 1) for parity-pure operands (st->dense_n)
     const int n2 = st->dense_n ? st->dense_n : n;
     const uint32_t N = 1u << n2, NROW = 1u << n;
-    const int L = st->use_mfma ? 5 : 4;
+    const int L = st->use_mfma ? 5 : st->use_mfma7 ? 3 : 4;
     // operands: a fixed pseudo-random row each (exact small integers: every sum below is exact)
     std::vector<double> lrow(NROW), rrow(NROW);
     uint64_t x = 88172645463325252ULL;
@@ -140,9 +149,10 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     for (uint32_t i = 0; i < NROW; ++i) lrow[i] = rnd();
     for (uint32_t i = 0; i < NROW; ++i) rrow[i] = rnd();
     // images in permuted-blade order
-    std::vector<uint32_t> inv_vec(N), inv_b(N);
+    std::vector<uint32_t> inv_vec(N), inv_b(N), inv_a7(256, 0);
     for (uint32_t m = 0; m < N; ++m) inv_vec[vec_pos(m)] = m;
-    if (st->mfma32_pairs) for (uint32_t m = 0; m < N; ++m) inv_b[mfma32p_b_pos(m)] = m;
+    if (st->use_mfma7) for (uint32_t m = 0; m < N; ++m) { inv_b[mfma7_b_pos(m)] = m; inv_a7[mfma7_a_pos(m)] = m; }
+    else if (st->mfma32_pairs) for (uint32_t m = 0; m < N; ++m) inv_b[mfma32p_b_pos(m)] = m;
     else if (st->use_mfma) for (uint32_t m = 0; m < N; ++m) inv_b[mfma_b_pos(m)] = m;
     else if (st->mfma16_quads) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16q_b_pos(m)] = m;
     else if (st->use_mfma16d) for (uint32_t m = 0; m < N; ++m) inv_b[mfma16d_b_pos(m)] = m;
@@ -156,12 +166,15 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
         size_t idx = 0;
         for (uint32_t w : map) {
             const uint32_t off = w & 0xffffu, pos = (w >> 16) & 0x7fffu;
-            const uint32_t blade = (st->use_mfma || st->use_mfma16) ? (right ? inv_b[pos] : pos) : inv_vec[pos];
+            const uint32_t blade = st->use_mfma7 ? (right ? inv_b[pos] : inv_a7[pos])
+                                   : (st->use_mfma || st->use_mfma16) ? (right ? inv_b[pos] : pos) : inv_vec[pos];
             uint32_t neg = w >> 31;
             // the image-pair kernels keep the b_hi part of (-1)^(|a_hi| |b_lo|) in the B image (the kernel supplies the
             // c_hi part): taken out again here, the plain formula below applies
             if (right && (st->use_mfma16 || st->mfma32_pairs))
                 neg ^= uint32_t(__builtin_popcount(blade >> L) & __builtin_popcount(blade & ((1u << L) - 1u)) & 1);
+            if (right && st->use_mfma7)   // the hi3 part only: the top vector's share is in the kernel's A and result signs
+                neg ^= uint32_t(__builtin_popcount((blade >> 3) & 7u) & __builtin_popcount(blade & 7u) & 1);
             img[blade] = (neg ? -row[off] : row[off]) * (st->scaled ? scale[idx] : 1.0);
             ++idx;
         }
@@ -324,7 +337,12 @@ int main() {
         dense_tables_agree_with_the_list(8, gen8, GAAST_F64, 0, "mfma16x4 f64 tables n=8 general metric", "rescaled basis");
         dense_tables_agree_with_the_list(8, gen8z, GAAST_F64, 0, "mfma16x4 f64 tables n=8 general metric with null vectors", "rescaled basis");
         dense_tables_agree_with_the_list(8, gen8, GAAST_F64, GAAST_FLAG_NO_MFMA, "vector tables n=8 general metric", "rescaled basis");
-        dense_tables_agree_with_the_list(7, gen7, GAAST_F32, 0, "vector tables n=7 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(7, gen7, GAAST_F32, 0, "mfma7 tables n=7 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(7, gen7, GAAST_F64, GAAST_FLAG_NO_MFMA, "vector tables n=7 general metric", "rescaled basis");
+        dense_tables_agree_with_the_list(7, euclid, GAAST_F64, 0, "mfma7 tables n=7 euclid", "product_dense_mfma[gp n=7]");
+        dense_tables_agree_with_the_list(7, mix8, GAAST_F32, 0, "mfma7 tables n=7 mixed", "product_dense_mfma[gp n=7");
+        dense_tables_agree_with_the_list(7, pga8, GAAST_F64, 0, "mfma7 tables n=7 null vector first", "permuted basis");
+        dense_tables_agree_with_the_list(8, mix8, GAAST_F64, 0, "parity-pure n=8 -> mfma7 even x odd", "even x odd in Cl(7)", 0x155, 0x0aa);
         dense_tables_agree_with_the_list(10, gen10, GAAST_F32, 0, "mfma32p tables n=10 general metric", "rescaled basis");
         dense_tables_agree_with_the_list(10, gen10, GAAST_F64, 0, "mfma16x4 f64 tables n=10 general metric", "rescaled basis");
         // parity-pure operands: one product in the even subalgebra Cl(n - 1) (plan.cpp: parity_reduced_frame), all four

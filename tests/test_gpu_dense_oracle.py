@@ -376,7 +376,8 @@ def _oracle_and_hip(build, alg, rows, batch, dtype=ga.F64, flags=0):
     (9, ga.F64, "even", "k_gp_mfma16x4<double,false,8,"),        # register-prefetch staging, the list reads OTHER rows than the right operand
     (9, ga.F64, "partial", "k_gp_mfma16x4<double,false,8,"),     # right operand misses a grade: general staging of a chained step
     (9, ga.F32, "even", "k_gp_mfma16x4<float,false,8,"),
-    (8, ga.F32, "even", "k_gp_dense<float,false,256,"),          # Cl(7): the vector kernel, 32 items per workgroup
+    (8, ga.F32, "even", "k_gp_mfma7<float,"),              # Cl(7): one wave per item
+    (8, ga.F64, "partial", "k_gp_mfma7<double,"),          # ... general staging of a chained step
     (11, ga.F32, "even", "k_gp_mfma32p<false,10,false,true>"),   # Cl(10): k_gp_mfma32p's general staging
 ])
 def test_chained_products_with_unrelated_operands(n, dtype, right_grades, kernel):
@@ -428,3 +429,75 @@ def test_parity_pure_products_accumulate_and_project():
             assert np.all(np.abs(got[i] - want[i]) <= 4 * 2.0 ** -52 * bits_to_row(n, [2], S) + 1e-300)
     else:
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("metric", [[1.0] * 7, [-1.0] * 7, [1.0, 1.0, 1.0, -1.0, 1.0, -1.0, -1.0], [0.0, 1.0, -1.0, 1.0, 0.0, 1.0, 1.0],
+                                    [1.0, -1.0, 1.0, 1.0, -1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0, -1.0, 1.0, 0.0],
+                                    [2.0, 0.5, -3.0, 1.0, 0.0, -0.25, 1.5]])
+def test_n7_one_wave_per_item_on_the_matrix_cores(metric):
+    """k_gp_mfma7<T> (both value types): the top basis vector split over the rows and columns of the 16 x 16 tile, the two halves
+    of every component joined by a lane exchange.  Signatures with -1 / 0 in the lo bits' candidates (permuted basis), in the
+    hi3 bits (zero words) and on the top vector (its square enters the result sign / drops the u = v = 1 half); a general metric
+    (rescaled basis).  Full rows: register-prefetch staging and straight-line stores (MODE 2); behind GAAST_FLAG_NO_MFMA the
+    vector kernel where it applies."""
+    n = 7
+    general = any(m not in (1.0, -1.0, 0.0) for m in metric)
+    dg = "true" if 0.0 in metric else "false"
+    variants = [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma7<float,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma7<double,")]
+    if sum(m > 0 for m in metric) >= 4 or sum(m < 0 for m in metric) >= 4:
+        variants += [(ga.F64, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<double,{dg},256,"), (ga.F32, ga.FLAG_NO_MFMA, "product_dense[", f"k_gp_dense<float,{dg},256,")]
+    _check(n, metric, None, variants, batch=70, seed=770, eps_factor=8 if general else 4, exact_order_too=general)
+
+
+@pytest.mark.parametrize("left_grades,out_grades", [([0, 1, 2, 3, 4, 5], None), (None, [0, 2, 3, 5, 7]), ([1, 2, 3, 4, 5, 6, 7], [1, 2, 4, 6])])
+def test_n7_general_staging_and_partial_results(left_grades, out_grades):
+    """k_gp_mfma7 through its general staging (a left operand that misses grades: MODE 0) and its general stores (a projected
+    result: MODE 1 with full operands), in a mixed signature with a permuted basis"""
+    n = 7
+    metric = [-1.0, 1.0, 1.0, -1.0, 1.0, 0.0, -1.0]
+    lg = full_grades(n) if left_grades is None else left_grades
+    og_sel = full_grades(n) if out_grades is None else out_grades
+    build = lambda B: (B.input(0, lg, n) * B.input(1, full_grades(n), n)).gselect(og_sel)
+    batch = 33
+    for dtype in (ga.F32, ga.F64):
+        rng = np.random.default_rng(771)
+        rows = {0: rows_of(n, lg, batch, rng, np.float32), 1: rows_of(n, full_grades(n), batch, rng, np.float32)}
+        rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+        want, wmask = oracle_eval_batch(build, metric, rows64, batch)
+        got, mask, spec = hip_eval_batch(build, metric, rows if dtype == ga.F32 else rows64, batch, dtype=dtype)
+        assert mask == wmask
+        assert any("k_gp_mfma7<" in l for l in spec.launches()), spec.launches()
+        og = [k for k in range(n + 1) if (wmask >> k) & 1]
+        eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+        for i in range(batch):
+            S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, full_grades(n), rows64[1][i]))
+            bound = 4 * eps * bits_to_row(n, og, S) + 1e-300
+            err = np.abs(got[i].astype(np.float64) - want[i])
+            assert np.all(err <= bound), (dtype, i, float((err / bound).max()))
+
+
+def test_n7_products_accumulate():
+    """a b + c d at n = 7: the second k_gp_mfma7 launch adds into the buffer the first one wrote (beta = 1: general stores)"""
+    n, batch = 7, 19
+    fg = full_grades(n)
+    rng = np.random.default_rng(772)
+    rows = {s_: rows_of(n, fg, batch, rng) for s_ in range(4)}
+    build = lambda B: B.input(0, fg, n) * B.input(1, fg, n) + B.input(2, fg, n) * B.input(3, fg, n)
+    want, got, spec = _oracle_and_hip(build, n, rows, batch)
+    assert sum("k_gp_mfma7<double" in l for l in spec.launches()) == 2, spec.launches()
+    for i in range(batch):
+        S = sum(abs_terms_bound(n, row_to_bits(n, fg, rows[a][i]), row_to_bits(n, fg, rows[b][i])) for a, b in ((0, 1), (2, 3)))
+        bound = 5 * 2.0 ** -52 * bits_to_row(n, fg, S) + 1e-300
+        assert np.all(np.abs(got[i] - want[i]) <= bound), i
+
+
+@pytest.mark.parametrize("lpar,rpar", [("even", "even"), ("even", "odd"), ("odd", "even"), ("odd", "odd")])
+@pytest.mark.parametrize("metric", [[1.0] * 8, [1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 0.0, -1.0]])
+def test_n8_parity_pure_products_run_in_cl7_on_the_matrix_cores(lpar, rpar, metric):
+    """rotor composition and the products of odd versors at n = 8: ONE product in Cl(7) on k_gp_mfma7 (round 3's first half ran
+    them on the vector kernel at 1.8x the full product)"""
+    n = 8
+    grades = {"even": EVEN(n), "odd": ODD(n)}
+    dg = "true" if 0.0 in metric else "false"
+    _check(n, metric, grades[lpar], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma7<float,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma7<double,")],
+           batch=21, seed=780, right_grades=grades[rpar], label_has=f"{lpar} x {rpar} in Cl(7)")
