@@ -282,4 +282,183 @@ __global__ __launch_bounds__(256) void k_product_ell(EllArgs<T> p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_product_ell_chain: TWO list products in one launch -- list 1's result (the "mid" row) is read only by list 2, as one of its
+// operands: (R X) ~R projected on a grade, the rotor sandwich applied to a vector (eval.rs:61-86 with its cached operand; README.md:62-67)
+// at the dimensions where the program no longer fits a fused small-program kernel and the second product is too sparse for the
+// dense kernels (n rows of 2^(n-1) terms).  Both lists keep the reference's order and roundings (eval.rs:82), the mid row is
+// canonicalised as the second product's operand staging would have (0.0 + x, eval.rs:27-31): bit for bit the two-launch plan,
+// without the mid row's round trip through HBM and with every lane busy in the second list:
+//   * a workgroup stages the operand rows of IPB items (a power of two; about 36 KiB of LDS, so that four workgroups share a CU
+//     and one's staging overlaps another's lists) in LDS, item i at i * item_stride elements with item_stride = 1 (mod 32):
+//     lanes that read the SAME offset of consecutive items touch different banks;
+//   * list 1 (many short rows): a thread takes a row and walks the items with the row's words in registers;
+//   * list 2 (few long rows) runs over (row, item) pairs, item fastest -- its n rows occupy n x IPB lanes instead of n -- with its
+//     words in LDS (copied once per persistent workgroup): no cache round trip inside a row's chain of additions.
+// Entries: left offset [14:0] | right offset [30:16] | negate [31], offsets in BYTES (rows of at most 32 KiB).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct EllChainArgs {
+    const T* l1;
+    const T* r1;
+    const T* r2;
+    T* out;
+    int64_t l1_stride, r1_stride, r2_stride, out_stride;
+    int l1_len, r1_len, r2_len, mid_len;
+    int canon_l1, canon_r1, canon_r2, canon_mid;
+    const uint32_t* ent1;   // [width1][rows1]
+    const uint32_t* pos1;   // element offset of each row of list 1 in the mid row
+    int rows1, width1;
+    const uint32_t* ent2;   // [width2][rows2]
+    const uint32_t* out2;   // output offset of each row of list 2
+    int rows2, width2;
+    int mid_is_left;        // list 2 reads the mid row as its left (1) or right (0) operand
+    int r2_alias;           // list 2's other operand: 0 = a row of its own (r2), 1 = list 1's left row, 2 = list 1's right row
+    int mid_covered;        // every component of the mid row is a row of list 1 (else the rest is zero)
+    int beta;
+    int ipb_log2, item_stride;
+    int ent2_lds_bytes;     // > 0: list 2's words are copied to LDS once per (persistent) workgroup; a multiple of 16
+    int64_t batch;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void k_product_ell_chain(EllChainArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ipb = 1 << p.ipb_log2;
+    const T zero = T(0);
+    // LDS: [list 2's words, when they fit (ent2_lds)] then per item [list 1 left | list 1 right | mid | list 2's own operand]
+    uint32_t* ent2_lds = reinterpret_cast<uint32_t*>(smem_raw);
+    T* smem = reinterpret_cast<T*>(smem_raw + p.ent2_lds_bytes);
+    // ([row][term] with rows 4 words apart in the banks: a lane's next eight words are two 16-byte reads, lanes of one row read one address)
+    const int ent2_row = p.width2 + 4;
+    if (p.ent2_lds_bytes)
+        for (int e = tid; e < p.rows2 * p.width2; e += nthr) {
+            const int t = e / p.rows2, row = e - t * p.rows2;
+            ent2_lds[row * ent2_row + t] = p.ent2[e];
+        }
+    const int off_r1 = p.l1_len, off_mid = off_r1 + p.r1_len, off_r2 = off_mid + p.mid_len;
+    const int stride_b = p.item_stride * int(sizeof(T));
+    const char* sb = reinterpret_cast<const char*>(smem);
+    const int off_other = (p.r2_alias == 1 ? 0 : p.r2_alias == 2 ? off_r1 : off_r2) * int(sizeof(T));
+    const int off_l = p.mid_is_left ? off_mid * int(sizeof(T)) : off_other, off_r = p.mid_is_left ? off_other : off_mid * int(sizeof(T));
+    auto term = [&](uint32_t e, const char* l, const char* r, T a) -> T {   // eval.rs:82 with coeff = +-1
+        return a + ell_flip(*reinterpret_cast<const T*>(l + (e & 0x7fffu)) * *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu)), e & 0x80000000u);
+    };
+    const int64_t groups = (p.batch + ipb - 1) >> p.ipb_log2;
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {   // persistent workgroups: list 2's words are fetched once
+        const int64_t item0 = g << p.ipb_log2;
+        const int nitems = int(p.batch - item0 < ipb ? p.batch - item0 : ipb);
+        // operand rows of the group's items: element e = it * len + c of a flattened (item, component) range, four loads in
+        // flight per thread (the split by a run-time length is a float reciprocal and one correction step, valid below 2^24)
+        auto stage = [&](const T* src, int64_t stride, int len, int canon, int off) {
+            const int total = nitems * len;
+            const float inv = 1.0f / float(len > 0 ? len : 1);
+            for (int e0 = tid; e0 < total; e0 += 4 * nthr) {
+                T v[4];
+                int dst[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * nthr;
+                    int it = int(float(e) * inv), c = e - it * len;
+                    if (c < 0) {
+                        --it;
+                        c += len;
+                    }
+                    if (c >= len) {
+                        ++it;
+                        c -= len;
+                    }
+                    dst[k] = e < total ? it * p.item_stride + off + c : -1;
+                    v[k] = e < total ? src[(item0 + it) * stride + c] : zero;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (dst[k] >= 0) smem[dst[k]] = canon ? zero + v[k] : v[k];
+            }
+        };
+        stage(p.l1, p.l1_stride, p.l1_len, p.canon_l1, 0);
+        stage(p.r1, p.r1_stride, p.r1_len, p.canon_r1, off_r1);
+        if (!p.r2_alias) stage(p.r2, p.r2_stride, p.r2_len, p.canon_r2, off_r2);
+        if (!p.mid_covered)
+            for (int it = 0; it < nitems; ++it)
+                for (int c = tid; c < p.mid_len; c += nthr) smem[it * p.item_stride + off_mid + c] = zero;
+        __syncthreads();
+        // ---- list 1 -> mid: a thread takes a ROW and walks the group's items with the row's words in registers (rows of up to 16
+        // terms -- R X has n; longer rows re-read their words from L1 per item): one fetch of the words per row and group ----
+        for (int row = tid; row < p.rows1; row += nthr) {
+            const uint32_t* ep = p.ent1 + row;
+            // the row's words, decoded once: byte offsets from the item's left row (the right row sits off_r1 further) and the sign
+            uint32_t lo[16], ro[16], sg[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t e = j < p.width1 ? ep[size_t(j) * p.rows1] : 0u;
+                lo[j] = e & 0x7fffu;
+                ro[j] = ((e >> 16) & 0x7fffu) + uint32_t(off_r1) * uint32_t(sizeof(T));
+                sg[j] = e & 0x80000000u;
+            }
+            const int pos = off_mid + int(p.pos1[row]);
+            for (int it = 0; it < nitems; ++it) {
+                const char* l = sb + it * stride_b;
+                T acc = zero;                               // the fresh cache buffer of eval.rs:21-33
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < p.width1) acc = acc + ell_flip(*reinterpret_cast<const T*>(l + lo[j]) * *reinterpret_cast<const T*>(l + ro[j]), sg[j]);   // eval.rs:82, coeff = +-1
+                for (int t = 16; t < p.width1; ++t) acc = term(ep[size_t(t) * p.rows1], l, l + off_r1 * int(sizeof(T)), acc);
+                smem[it * p.item_stride + pos] = p.canon_mid ? zero + acc : acc;
+            }
+        }
+        __syncthreads();
+        // ---- list 2: (mid, other operand) -> out, over (row, item) pairs, item fastest: its few rows fill rows2 x IPB lanes ----
+        {
+            const int pairs = p.rows2 << p.ipb_log2;
+            for (int w = tid; w < pairs; w += nthr) {
+                const int row = w >> p.ipb_log2, it = w & (ipb - 1);
+                if (it >= nitems) continue;
+                const char* l = sb + it * stride_b + off_l;
+                const char* r = sb + it * stride_b + off_r;
+                T* o = p.out + (item0 + it) * p.out_stride + p.out2[row];
+                T acc = p.beta ? *o : zero;
+                int t = 0;
+                if (p.ent2_lds_bytes) {
+                    const uint32_t* ep = ent2_lds + row * ent2_row;
+                    for (; t + 8 <= p.width2; t += 8) {
+                        uint32_t ev[8];
+                        {
+                            const uint4 q0 = *reinterpret_cast<const uint4*>(ep + t), q1 = *reinterpret_cast<const uint4*>(ep + t + 4);
+                            ev[0] = q0.x; ev[1] = q0.y; ev[2] = q0.z; ev[3] = q0.w;
+                            ev[4] = q1.x; ev[5] = q1.y; ev[6] = q1.z; ev[7] = q1.w;
+                        }
+                        T prod[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            prod[j] = ell_flip(*reinterpret_cast<const T*>(l + (ev[j] & 0x7fffu)) * *reinterpret_cast<const T*>(r + ((ev[j] >> 16) & 0x7fffu)),
+                                               ev[j] & 0x80000000u);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = acc + prod[j];
+                    }
+                    for (; t < p.width2; ++t) acc = term(ep[t], l, r, acc);
+                } else {
+                    const uint32_t* ep = p.ent2 + row;
+                    for (; t + 8 <= p.width2; t += 8) {
+                        uint32_t ev[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ev[j] = ep[size_t(t + j) * p.rows2];
+                        T prod[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            prod[j] = ell_flip(*reinterpret_cast<const T*>(l + (ev[j] & 0x7fffu)) * *reinterpret_cast<const T*>(r + ((ev[j] >> 16) & 0x7fffu)),
+                                               ev[j] & 0x80000000u);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = acc + prod[j];
+                    }
+                    for (; t < p.width2; ++t) acc = term(ep[size_t(t) * p.rows2], l, r, acc);
+                }
+                *o = acc;
+            }
+        }
+        __syncthreads();   // the rows are rewritten by the next group
+    }
+}
+
 }  // namespace gaast

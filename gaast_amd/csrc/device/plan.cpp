@@ -1659,6 +1659,99 @@ static void chain_sparse_into_dense(Plan& plan) {
     plan.steps = std::move(kept);
 }
 
+// A list product whose result is read ONLY by another list product (as either operand): both run in ONE k_product_ell_chain
+// launch with the mid row in LDS -- the rotor sandwich applied to a vector, (R X ~R).g(1), where it no longer fits a fused
+// small-program kernel (n >= 9) and its second product (n rows of 2^(n-1) terms) is far too sparse for the dense kernels.  Same
+// order, same roundings: bit for bit the two-launch plan.  Off with GAAST_FLAG_DEBUG_NO_CHAIN.
+static void chain_list_into_list(Plan& plan) {
+    if (plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_DEBUG_NO_CHAIN)) return;
+    if (plan.node_dead.size() != plan.node_buffers.size()) plan.node_dead.assign(plan.node_buffers.size(), 0);
+    const size_t elem = plan.dtype == GAAST_F32 ? 4 : 8;
+    auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
+    auto row_len = [&](BufRef r) -> int64_t {
+        return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)].row_len : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)].row_len
+                                                                                                           : plan.out_layout.row_len;
+    };
+    for (const Step& t : plan.steps)
+        if (t.kind == Step::FUSED) return;
+    for (size_t j = 0; j < plan.steps.size(); ++j) {
+        Step& c = plan.steps[j];
+        if (c.kind != Step::PRODUCT_CSR || c.ell_width <= 0 || !c.ell_bytes || c.list_chain) continue;
+        for (int side = 1; side <= 2 && !c.list_chain; ++side) {
+            const BufRef buf = side == 1 ? c.a : c.b, other = side == 1 ? c.b : c.a;
+            if (buf.kind != BufKind::NODE || buf.idx < 0 || same(buf, other)) continue;
+            int writer = -1;
+            bool ok = true;
+            for (size_t i = 0; i < plan.steps.size() && ok; ++i) {
+                const Step& t = plan.steps[i];
+                if (i == j) continue;
+                if (same(t.res, buf)) {
+                    if (writer >= 0 || t.kind != Step::PRODUCT_CSR || t.ell_width <= 0 || !t.ell_bytes || t.beta != 0 || t.list_chain || i > j) ok = false;
+                    writer = int(i);
+                }
+                if ((t.a.idx >= 0 && same(t.a, buf)) || (t.b.idx >= 0 && same(t.b, buf))) ok = false;
+                if ((t.chained || t.list_chain) && (same(t.pre_a, buf) || same(t.pre_b, buf))) ok = false;
+            }
+            if (!ok || writer < 0) continue;
+            Step& w = plan.steps[size_t(writer)];
+            if (same(w.a, buf) || same(w.b, buf) || same(c.res, w.a) || same(c.res, w.b)) continue;
+            for (size_t i = size_t(writer) + 1; i < j && ok; ++i)
+                if (same(plan.steps[i].res, w.a) || same(plan.steps[i].res, w.b)) ok = false;
+            if (!ok) continue;
+            const int64_t l1 = row_len(w.a), r1 = row_len(w.b), mid = row_len(buf), r2 = row_len(other);
+            const int canon_other = side == 1 ? c.canon_b : c.canon_a;
+            int alias = 0;
+            if (same(other, w.a) && canon_other == w.canon_a) alias = 1;
+            else if (same(other, w.b) && canon_other == w.canon_b) alias = 2;
+            const int64_t per_item = l1 + r1 + mid + (alias ? 0 : r2);
+            if (per_item * int64_t(elem) >= 32768 * 3) continue;       // byte offsets of the entries stay below 32 KiB per row anyway
+            int64_t stride = per_item;
+            while (stride % 32 != 1) ++stride;                         // consecutive items: consecutive banks
+            // items per workgroup: about 36 KiB of LDS (four workgroups per CU: one's staging overlaps another's lists), at least
+            // four items when that still fits the CU
+            // this list's words ride in LDS when they take at most 48 KiB (n <= 11 for the sandwich)
+            int64_t ent2 = ((int64_t(c.ell_width) + 4) * int64_t(c.u32_b.size()) * 4 + 15) / 16 * 16;   // [row][term], rows 4 words apart; widths are multiples of 4
+            if (ent2 > 48 * 1024 || c.ell_width % 4) ent2 = 0;
+            int ipb_log2 = 6;
+            while (ipb_log2 > 2 && (int64_t(1) << ipb_log2) * stride * int64_t(elem) > 36 * 1024) --ipb_log2;
+            if (ent2 + (int64_t(1) << ipb_log2) * stride * int64_t(elem) > int64_t(kLdsBytes) - 16 * 1024) ent2 = 0;
+            if ((int64_t(1) << ipb_log2) * stride * int64_t(elem) > int64_t(kLdsBytes) - 16 * 1024) continue;
+            c.chain_ent2_lds = int(ent2);
+            // rows of the first list -> their element offsets in the mid row; is every component of the mid row produced?
+            std::vector<char> produced(size_t(mid), 0);
+            for (uint32_t off : w.u32_b) produced[off] = 1;
+            bool covered = true;
+            for (char x : produced) covered = covered && x;
+            c.list_chain = side;
+            c.chain_alias = alias;
+            c.chain_mid_len = int(mid);
+            c.chain_canon_mid = side == 1 ? c.canon_a : c.canon_b;
+            c.chain_covered = covered ? 1 : 0;
+            c.chain_ipb_log2 = ipb_log2;
+            c.chain_item_stride = int(stride);
+            c.pre_a = w.a;
+            c.pre_b = w.b;
+            c.pre_canon_a = w.canon_a;
+            c.pre_canon_b = w.canon_b;
+            c.pre_left_len = int(l1);
+            c.pre_right_len = int(r1);
+            c.pre_entries = w.u32_c;
+            c.pre_row_map = w.u32_b;
+            c.pre_width = w.ell_width;
+            c.name += " <- " + w.name + " in LDS";
+            c.n_entries += w.n_entries;
+            (side == 1 ? c.a : c.b) = BufRef{BufKind::NODE, -1};
+            plan.node_dead[size_t(buf.idx)] = 1;
+            w.kind = Step::ZERO;   // marks the first list for removal below
+            w.res = BufRef{BufKind::NODE, -1};
+        }
+    }
+    std::vector<Step> kept;
+    for (Step& t : plan.steps)
+        if (!(t.kind == Step::ZERO && t.res.kind == BufKind::NODE && t.res.idx < 0)) kept.push_back(std::move(t));
+    plan.steps = std::move(kept);
+}
+
 void build_plan(const gaast_program_desc& desc, Plan& plan) {
     if (desc.vec_space_dim < 0 || desc.vec_space_dim > GAAST_MAX_DIM) throw std::runtime_error("vec_space_dim out of range");
     if (desc.n_nodes <= 0 || desc.root < 0 || desc.root >= desc.n_nodes) throw std::runtime_error("bad node count / root");
@@ -1718,6 +1811,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
     if (!try_fuse(plan)) {
         chain_sparse_into_dense(plan);
         uniform_csr_to_ell(plan);
+        chain_list_into_list(plan);
     }
 }
 

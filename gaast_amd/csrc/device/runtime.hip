@@ -219,6 +219,17 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             return set_err(GAAST_ERR_UNIMPLEMENTED,
                            "product operands of " + std::to_string(per_item) + " bytes per item do not fit the " +
                                std::to_string(g_max_lds) + "-byte LDS of the list kernels (" + s.name + ")");
+        if (s.list_chain) {
+            // two lists in one launch, the mid row in LDS (plan.cpp: chain_list_into_list): IPB items per workgroup
+            s.lds = size_t(s.chain_ent2_lds) + (size_t(s.chain_item_stride) << s.chain_ipb_log2) * sizeof(T);
+            if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "list chain does not fit in LDS (" + s.name + ")");
+            const int64_t pairs2 = int64_t(s.u32_b.size()) << s.chain_ipb_log2;
+            s.threads = int(std::min<int64_t>(512, std::max<int64_t>(256, (pairs2 + 63) / 64 * 64)));
+            s.kern[0] = reinterpret_cast<const void*>(&k_product_ell_chain<T>);
+            s.hip_kernel = "k_product_ell_chain<" + tn + ">";
+            if (int st = allow_lds(s.kern[0], s.lds)) return st;
+            return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
+        }
         s.lds = per_item;
         s.threads = 256;
         if (s.ell_width > 0) {
@@ -429,6 +440,48 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         break;
     }
     case Step::PRODUCT_CSR: {
+        if (s.list_chain) {
+            EllChainArgs<T> q;
+            const bool mid_left = s.list_chain == 1;
+            const Bound& other = mid_left ? b : a;
+            const Layout& lo = mid_left ? lb : la;
+            q.l1 = static_cast<const T*>(pre_a.ptr);
+            q.r1 = static_cast<const T*>(pre_b.ptr);
+            q.r2 = static_cast<const T*>(other.ptr);
+            q.out = static_cast<T*>(res.ptr);
+            q.l1_stride = pre_a.stride;
+            q.r1_stride = pre_b.stride;
+            q.r2_stride = other.stride;
+            q.out_stride = res.stride;
+            q.l1_len = s.pre_left_len;
+            q.r1_len = s.pre_right_len;
+            q.r2_len = int(lo.row_len);
+            q.mid_len = s.chain_mid_len;
+            q.canon_l1 = s.pre_canon_a;
+            q.canon_r1 = s.pre_canon_b;
+            q.canon_r2 = mid_left ? s.canon_b : s.canon_a;
+            q.canon_mid = s.chain_canon_mid;
+            q.ent1 = static_cast<const uint32_t*>(s.d_pre_entries);
+            q.pos1 = static_cast<const uint32_t*>(s.d_pre_row_map);
+            q.rows1 = int(s.pre_row_map.size());
+            q.width1 = s.pre_width;
+            q.ent2 = static_cast<const uint32_t*>(s.d_c);
+            q.out2 = static_cast<const uint32_t*>(s.d_b);
+            q.rows2 = int(s.u32_b.size());
+            q.width2 = s.ell_width;
+            q.mid_is_left = mid_left ? 1 : 0;
+            q.r2_alias = s.chain_alias;
+            q.mid_covered = s.chain_covered;
+            q.beta = s.beta;
+            q.ipb_log2 = s.chain_ipb_log2;
+            q.item_stride = s.chain_item_stride;
+            q.batch = batch;
+            q.ent2_lds_bytes = s.chain_ent2_lds;
+            int64_t blocks = (batch + (int64_t(1) << s.chain_ipb_log2) - 1) >> s.chain_ipb_log2;
+            if (s.blocks_per_cu > 0) blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * s.blocks_per_cu);
+            hipLaunchKernelGGL(k_product_ell_chain<T>, dim3(unsigned(blocks)), dim3(unsigned(s.threads)), s.lds, g_stream, q);
+            break;
+        }
         if (s.ell_width > 0) {
             EllArgs<T> q;
             q.left = static_cast<const T*>(a.ptr);
@@ -838,6 +891,12 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
             if (int st = upload_t(s.pre_coeff, &s.d_pre_coeff)) return st;
             if (int st = upload_t(s.pre_row_scale, &s.d_pre_row_scale)) return st;
         }
+        if (s.list_chain) {
+            if (s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
+            if (s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
+            if (int st = upload_vec(s.pre_entries, &s.d_pre_entries)) return st;
+            if (int st = upload_vec(s.pre_row_map, &s.d_pre_row_map)) return st;
+        }
         if (s.a.idx >= 0 && s.a.kind == BufKind::INPUT) plan.slot_used[size_t(s.a.idx)] = 1;
         if (s.b.idx >= 0 && s.b.kind == BufKind::INPUT) plan.slot_used[size_t(s.b.idx)] = 1;
         for (const Step::FusedInput& fi : s.fused_inputs) plan.slot_used[size_t(fi.slot)] = 1;
@@ -1135,7 +1194,7 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         if (s.b.idx >= 0) b = resolve(s.b, &lb);
         const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;
         Bound pa{nullptr, 0}, pb{nullptr, 0};
-        if (s.chained) {
+        if (s.chained || s.list_chain) {
             Layout unused;
             pa = resolve(s.pre_a, &unused);
             pb = resolve(s.pre_b, &unused);

@@ -501,3 +501,52 @@ def test_n8_parity_pure_products_run_in_cl7_on_the_matrix_cores(lpar, rpar, metr
     dg = "true" if 0.0 in metric else "false"
     _check(n, metric, grades[lpar], [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma7<float,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma7<double,")],
            batch=21, seed=780, right_grades=grades[rpar], label_has=f"{lpar} x {rpar} in Cl(7)")
+
+
+@pytest.mark.parametrize("n,metric", [(9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (11, [1.0] * 11), (12, [1.0] * 4 + [-1.0] * 8)])
+def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
+    """(R X ~R).g(1), the rotor sandwich applied to a vector (README.md:62-67; eval.rs:61-86 with the cached R X), where the program
+    no longer fits a fused small-program kernel: both products are lists (n 2^(n-1) entries each) and run in ONE
+    k_product_ell_chain launch with the mid row R X in LDS -- reference order and roundings, so the result equals the oracle's
+    and the two-launch plan's (GAAST_FLAG_DEBUG_NO_CHAIN) bit for bit.  The batch is not a multiple of the items a workgroup
+    stages."""
+    even = EVEN(n)
+    build = lambda B: (lambda r, x: (r * x * r.rev()).g(1))(B.input(0, even, n), B.input(1, [1], n))
+    batch = 37 if n < 11 else 11 if n == 11 else 5
+    rng = np.random.default_rng(900 + n)
+    rows = {0: rows_of(n, even, batch, rng), 1: rows_of(n, [1], batch, rng)}
+    alg = metric if any(m != 1.0 for m in metric) else n
+    want, wmask = oracle_eval_batch(build, alg, rows, batch)
+    got, mask, spec = hip_eval_batch(build, alg, rows, batch)
+    assert mask == wmask
+    assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and "k_product_ell_chain<double>" in spec.launches()[0], spec.launches()
+    assert np.array_equal(got, want)
+    two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN)
+    assert len(spec2.launches()) == 2 and np.array_equal(two, want), spec2.launches()
+
+
+@pytest.mark.parametrize("dtype", [ga.F64, ga.F32])
+def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtype):
+    """a (x b) with the mid row as the RIGHT operand of the second list; (a x) b with three different inputs (the second list stages a
+    row of its own); the second list adding into a buffer another product wrote (beta = 1); in both value types, bit-exact against the
+    oracle (f64) / the two-launch plan (f32: the oracle computes in f64)"""
+    n, batch = 9, 21
+    even = EVEN(n)
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(950)
+    rows = {0: rows_of(n, even, batch, rng, npdt), 1: rows_of(n, [1], batch, rng, npdt), 2: rows_of(n, even, batch, rng, npdt), 3: rows_of(n, [1], batch, rng, npdt)}
+    cases = [lambda B: (B.input(0, even, n) * (B.input(1, [1], n) * B.input(2, even, n))).g(1),
+             lambda B: ((B.input(0, even, n) * B.input(1, [1], n)) * B.input(2, even, n)).g(1),
+             lambda B: B.input(3, [1], n) + ((B.input(0, even, n) * B.input(1, [1], n)) * B.input(0, even, n).rev()).g(1)]
+    all_rows = rows
+    for k, build in enumerate(cases):
+        rows = {s_: all_rows[s_] for s_ in ((0, 1, 2), (0, 1, 2), (0, 1, 3))[k]}
+        got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+        two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
+        assert np.array_equal(got, two), (k, spec.launches(), spec2.launches())
+        if not any("ast_fused" in l for l in spec.launches()):     # (f32 slabs of the third program fit the LDS interpreter: one launch anyway)
+            assert any("k_product_ell_chain<" in l for l in spec.launches()), (k, spec.launches())
+            assert len(spec2.launches()) == len(spec.launches()) + 1, (k, spec.launches(), spec2.launches())
+        if dtype == ga.F64:
+            want, wmask = oracle_eval_batch(build, n, rows, batch)
+            assert mask == wmask and np.array_equal(got, want), k
