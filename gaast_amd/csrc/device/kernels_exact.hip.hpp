@@ -316,7 +316,7 @@ struct EllChainArgs {
     int r2_alias;           // list 2's other operand: 0 = a row of its own (r2), 1 = list 1's left row, 2 = list 1's right row
     int mid_covered;        // every component of the mid row is a row of list 1 (else the rest is zero)
     int beta;
-    int ipb_log2, item_stride;
+    int ipb, item_stride;   // items per workgroup (any count: rows2 x ipb is chosen just under a multiple of 64), elements per item in LDS
     int ent2_lds_bytes;     // > 0: list 2's words are copied to LDS once per (persistent) workgroup; a multiple of 16
     int64_t batch;
 };
@@ -325,7 +325,8 @@ template <typename T>
 __global__ __launch_bounds__(512) void k_product_ell_chain(EllChainArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int ipb = 1 << p.ipb_log2;
+    const int ipb = p.ipb;
+    const float inv_ipb = 1.0f / float(ipb);
     const T zero = T(0);
     // LDS: [list 2's words, when they fit (ent2_lds)] then per item [list 1 left | list 1 right | mid | list 2's own operand]
     uint32_t* ent2_lds = reinterpret_cast<uint32_t*>(smem_raw);
@@ -345,9 +346,9 @@ __global__ __launch_bounds__(512) void k_product_ell_chain(EllChainArgs<T> p) {
     auto term = [&](uint32_t e, const char* l, const char* r, T a) -> T {   // eval.rs:82 with coeff = +-1
         return a + ell_flip(*reinterpret_cast<const T*>(l + (e & 0x7fffu)) * *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu)), e & 0x80000000u);
     };
-    const int64_t groups = (p.batch + ipb - 1) >> p.ipb_log2;
+    const int64_t groups = (p.batch + ipb - 1) / ipb;
     for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {   // persistent workgroups: list 2's words are fetched once
-        const int64_t item0 = g << p.ipb_log2;
+        const int64_t item0 = g * ipb;
         const int nitems = int(p.batch - item0 < ipb ? p.batch - item0 : ipb);
         // operand rows of the group's items: element e = it * len + c of a flattened (item, component) range, four loads in
         // flight per thread (the split by a run-time length is a float reciprocal and one correction step, valid below 2^24)
@@ -411,9 +412,17 @@ __global__ __launch_bounds__(512) void k_product_ell_chain(EllChainArgs<T> p) {
         __syncthreads();
         // ---- list 2: (mid, other operand) -> out, over (row, item) pairs, item fastest: its few rows fill rows2 x IPB lanes ----
         {
-            const int pairs = p.rows2 << p.ipb_log2;
+            const int pairs = p.rows2 * ipb;
             for (int w = tid; w < pairs; w += nthr) {
-                const int row = w >> p.ipb_log2, it = w & (ipb - 1);
+                int row = int(float(w) * inv_ipb), it = w - row * ipb;   // w = row * ipb + it (w < 2^24: one correction step)
+                if (it < 0) {
+                    --row;
+                    it += ipb;
+                }
+                if (it >= ipb) {
+                    ++row;
+                    it -= ipb;
+                }
                 if (it >= nitems) continue;
                 const char* l = sb + it * stride_b + off_l;
                 const char* r = sb + it * stride_b + off_r;
@@ -422,6 +431,21 @@ __global__ __launch_bounds__(512) void k_product_ell_chain(EllChainArgs<T> p) {
                 int t = 0;
                 if (p.ent2_lds_bytes) {
                     const uint32_t* ep = ent2_lds + row * ent2_row;
+                    for (; t + 16 <= p.width2; t += 16) {   // sixteen terms: their words (four 16-byte reads) and 32 operand reads in flight, then the chain
+                        uint32_t ev[16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint4 w4 = *reinterpret_cast<const uint4*>(ep + t + 4 * q);
+                            ev[4 * q] = w4.x; ev[4 * q + 1] = w4.y; ev[4 * q + 2] = w4.z; ev[4 * q + 3] = w4.w;
+                        }
+                        T prod[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            prod[j] = ell_flip(*reinterpret_cast<const T*>(l + (ev[j] & 0x7fffu)) * *reinterpret_cast<const T*>(r + ((ev[j] >> 16) & 0x7fffu)),
+                                               ev[j] & 0x80000000u);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc = acc + prod[j];
+                    }
                     for (; t + 8 <= p.width2; t += 8) {
                         uint32_t ev[8];
                         {

@@ -1712,10 +1712,18 @@ static void chain_list_into_list(Plan& plan) {
             // this list's words ride in LDS when they take at most 48 KiB (n <= 11 for the sandwich)
             int64_t ent2 = ((int64_t(c.ell_width) + 4) * int64_t(c.u32_b.size()) * 4 + 15) / 16 * 16;   // [row][term], rows 4 words apart; widths are multiples of 4
             if (ent2 > 48 * 1024 || c.ell_width % 4) ent2 = 0;
-            int ipb_log2 = 6;
-            while (ipb_log2 > 2 && (int64_t(1) << ipb_log2) * stride * int64_t(elem) > 36 * 1024) --ipb_log2;
-            if (ent2 + (int64_t(1) << ipb_log2) * stride * int64_t(elem) > int64_t(kLdsBytes) - 16 * 1024) ent2 = 0;
-            if ((int64_t(1) << ipb_log2) * stride * int64_t(elem) > int64_t(kLdsBytes) - 16 * 1024) continue;
+            // items per workgroup: as many as make this list's (row, item) pairs just fill a wave (9 rows: 7 items = 63 lanes) -- a
+            // second, nearly empty wave would issue the whole list again --, fewer when the LDS does not hold them
+            const int64_t rows2 = int64_t(c.u32_b.size());
+            int64_t ipb = rows2 <= 32 ? 64 / rows2 : 4;
+            const int64_t lds_cap = int64_t(kLdsBytes) - 16 * 1024;
+            while (ipb > 2 && ent2 + ipb * stride * int64_t(elem) > lds_cap / 2) --ipb;   // two workgroups per CU when that costs at most ...
+            if (ipb < 4) {                                                                 // ... down to four items; then one workgroup per CU
+                ipb = std::min<int64_t>(rows2 <= 32 ? 64 / rows2 : 4, 4);
+                if (ent2 + ipb * stride * int64_t(elem) > lds_cap) ent2 = 0;
+                while (ipb > 1 && ipb * stride * int64_t(elem) > lds_cap) --ipb;
+            }
+            if (ipb < 2 || ent2 + ipb * stride * int64_t(elem) > lds_cap) continue;
             c.chain_ent2_lds = int(ent2);
             // rows of the first list -> their element offsets in the mid row; is every component of the mid row produced?
             std::vector<char> produced(size_t(mid), 0);
@@ -1727,7 +1735,7 @@ static void chain_list_into_list(Plan& plan) {
             c.chain_mid_len = int(mid);
             c.chain_canon_mid = side == 1 ? c.canon_a : c.canon_b;
             c.chain_covered = covered ? 1 : 0;
-            c.chain_ipb_log2 = ipb_log2;
+            c.chain_ipb = int(ipb);
             c.chain_item_stride = int(stride);
             c.pre_a = w.a;
             c.pre_b = w.b;

@@ -101,7 +101,7 @@ struct Step {
     int list_chain = 0;                  // 1: the mid row is this list's left operand, 2: its right operand
     int chain_alias = 0;                 // this list's other operand: 0 = a row of its own, 1 = the first list's left row, 2 = its right row
     int chain_mid_len = 0, chain_canon_mid = 0, chain_covered = 0;
-    int chain_ipb_log2 = 0, chain_item_stride = 0, chain_ent2_lds = 0;   // (bytes of this list's words kept in LDS, or 0)
+    int chain_ipb = 0, chain_item_stride = 0, chain_ent2_lds = 0;   // (bytes of this list's words kept in LDS, or 0)
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)

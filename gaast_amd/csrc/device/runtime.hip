@@ -221,9 +221,9 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                                std::to_string(g_max_lds) + "-byte LDS of the list kernels (" + s.name + ")");
         if (s.list_chain) {
             // two lists in one launch, the mid row in LDS (plan.cpp: chain_list_into_list): IPB items per workgroup
-            s.lds = size_t(s.chain_ent2_lds) + (size_t(s.chain_item_stride) << s.chain_ipb_log2) * sizeof(T);
+            s.lds = size_t(s.chain_ent2_lds) + size_t(s.chain_item_stride) * size_t(s.chain_ipb) * sizeof(T);
             if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "list chain does not fit in LDS (" + s.name + ")");
-            const int64_t pairs2 = int64_t(s.u32_b.size()) << s.chain_ipb_log2;
+            const int64_t pairs2 = int64_t(s.u32_b.size()) * s.chain_ipb;
             s.threads = int(std::min<int64_t>(512, std::max<int64_t>(256, (pairs2 + 63) / 64 * 64)));
             s.kern[0] = reinterpret_cast<const void*>(&k_product_ell_chain<T>);
             s.hip_kernel = "k_product_ell_chain<" + tn + ">";
@@ -473,11 +473,11 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
             q.r2_alias = s.chain_alias;
             q.mid_covered = s.chain_covered;
             q.beta = s.beta;
-            q.ipb_log2 = s.chain_ipb_log2;
+            q.ipb = s.chain_ipb;
             q.item_stride = s.chain_item_stride;
             q.batch = batch;
             q.ent2_lds_bytes = s.chain_ent2_lds;
-            int64_t blocks = (batch + (int64_t(1) << s.chain_ipb_log2) - 1) >> s.chain_ipb_log2;
+            int64_t blocks = (batch + s.chain_ipb - 1) / s.chain_ipb;
             if (s.blocks_per_cu > 0) blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * s.blocks_per_cu);
             hipLaunchKernelGGL(k_product_ell_chain<T>, dim3(unsigned(blocks)), dim3(unsigned(s.threads)), s.lds, g_stream, q);
             break;

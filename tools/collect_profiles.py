@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HIP_KERNEL = {"r12": "k_gp_mfma32p", "r8": "k_gp_mfma16x4<float>", "cl41": "gaast_jit", "cl41g1": "gaast_jit", "r12s": "k_gp_spinor12s",
               "r12d": "k_gp_mfma16x4<double>", "r8d": "k_gp_mfma16x4<double>", "sand9": "k_gp_mfma16x4<double,...,8,0,false,true> (chained)",
-              "sand10": "k_gp_mfma16x4<double,...,9,0,false,true> (chained)", "gp12f32ee": "k_gp_mfma32p<false,11>"}
+              "sand10": "k_gp_mfma16x4<double,...,9,0,false,true> (chained)", "gp12f32ee": "k_gp_mfma32p<false,11>",
+              "gp7f32": "k_gp_mfma7<float>", "sand8": "k_gp_mfma7<double,...,false,true> (chained)", "sand9g1": "k_product_ell_chain<double>"}
 
 
 def main():

@@ -31,6 +31,11 @@ stats gp9f32 --workload gp9f32 --no-alt
 stats gp10f32 --workload gp10f32 --no-alt
 stats gp12f32ee --workload gp12f32ee --no-alt
 stats gp12f64ee --workload gp12f64ee --no-alt
+stats gp7f32 --workload gp7f32 --no-alt
+stats gp8f32ee --workload gp8f32ee --no-alt
+stats gp8f64ee --workload gp8f64ee --no-alt
+stats sand9g1 --workload sand9g1 --no-alt
+stats sand10g1 --workload sand10g1 --no-alt
 stats sand8 --workload sand8 --no-alt
 stats sand9 --workload sand9 --no-alt
 stats sand10 --workload sand10 --no-alt
@@ -44,7 +49,7 @@ python3 bench.py --workload r8 > $out/bench_r8.json 2>/dev/null
 python3 bench.py --workload cl41 > $out/bench_cl41.json 2>/dev/null
 fi
 if [ $phase != stats ]; then
-for spec in "r12:k_gp_mfma32:--workload r12" "r8:k_gp_mfma16:--workload r8" "cl41:gaast_jit:--workload cl41" "cl41g1:gaast_jit:--workload cl41g1" "r12s:k_gp_spinor12s:--workload r12s" "r12d:k_gp_mfma16:--workload r12d" "r8d:k_gp_mfma16:--workload r8d" "sand9:k_gp_mfma16:--workload sand9" "sand10:k_gp_mfma16:--workload sand10" "gp12f32ee:k_gp_mfma32:--workload gp12f32ee"; do
+for spec in "r12:k_gp_mfma32:--workload r12" "r8:k_gp_mfma16:--workload r8" "cl41:gaast_jit:--workload cl41" "cl41g1:gaast_jit:--workload cl41g1" "r12s:k_gp_spinor12s:--workload r12s" "r12d:k_gp_mfma16:--workload r12d" "r8d:k_gp_mfma16:--workload r8d" "gp7f32:k_gp_mfma7:--workload gp7f32" "sand8:k_gp_mfma7:--workload sand8" "sand9g1:k_product_ell_chain:--workload sand9g1" "sand9:k_gp_mfma16:--workload sand9" "sand10:k_gp_mfma16:--workload sand10" "gp12f32ee:k_gp_mfma32:--workload gp12f32ee"; do
   name=${spec%%:*}; rest=${spec#*:}; kern=${rest%%:*}; args=${rest#*:}
   tools/pmc_pass.sh ${tag}_$name $kern $args > $out/pmc_$name.txt 2>&1
   cp gpurun_out/pmc_${tag}_$name/summary.csv $out/pmc_${name}_summary.csv
