@@ -994,7 +994,9 @@ struct Lowering {
 // Whole-plan fusion for small programs: every buffer becomes a region of a per-item LDS slab and
 // the steps become one micro-op stream (k_ast_fused).  Exact: same operations, same order.
 // ---------------------------------------------------------------------------------------------
-bool try_fuse(Plan& plan) {
+// slab_probe != nullptr: only report the slab size a fused plan would have (0: cannot be fused) and change nothing
+bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
+    if (slab_probe) *slab_probe = 0;
     if (plan.flags & GAAST_FLAG_NO_FUSION) return false;
     if (plan.error != GAAST_OK || plan.steps.empty()) return false;
     const size_t elem = plan.dtype == GAAST_F32 ? 4 : 8;
@@ -1052,6 +1054,10 @@ bool try_fuse(Plan& plan) {
     const int jit_slab_limit = plan.dtype == GAAST_F32 ? 200 : 160;
     const bool jit_allowed = !(plan.flags & GAAST_FLAG_NO_JIT) && slab <= jit_slab_limit;
     if (!interp_ok && !jit_allowed) return false;
+    if (slab_probe) {
+        *slab_probe = slab;
+        return false;
+    }
     auto base_of = [&](BufRef r, int canon = 0) {
         return r.kind == BufKind::NODE    ? node_base[size_t(r.idx)]
                : r.kind == BufKind::INPUT ? (canon ? in_base_canon : in_base)[size_t(r.idx)]
@@ -1816,6 +1822,19 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
         if (!lw.removed[i]) kept.push_back(std::move(plan.steps[i]));
     plan.steps = std::move(kept);
     plan.node_dead.assign(plan.node_buffers.size(), 0);
+    // A program that would only fit the LDS interpreter (its slab is beyond the registers of the hiprtc-specialised kernel) but is
+    // exactly one list chain -- (R X ~R).g(1) at n = 8 -- runs on k_product_ell_chain instead (same box: 1.43 against 1.59 ms per 1 M items)
+    int slab = 0;
+    try_fuse(plan, &slab);
+    if (slab > (plan.dtype == GAAST_F32 ? 200 : 160) && !(plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_DEBUG_NO_CHAIN | GAAST_FLAG_NO_JIT))) {
+        Plan trial = plan;
+        uniform_csr_to_ell(trial);
+        chain_list_into_list(trial);
+        if (trial.steps.size() == 1 && trial.steps[0].list_chain) {
+            plan = std::move(trial);
+            return;
+        }
+    }
     if (!try_fuse(plan)) {
         chain_sparse_into_dense(plan);
         uniform_csr_to_ell(plan);

@@ -141,7 +141,10 @@ struct Step {
 // limits of this back end (gfx950): a product whose staged operands exceed the LDS of a CU, or whose comp-mul list
 // exceeds the table budget, is valid in the reference but refused by gaast_hip_program_create (UNIMPLEMENTED)
 constexpr size_t kLdsBytes = 160 * 1024;
-constexpr size_t kInterpLdsBytes = 144 * 1024;   // slabs of the 64 items of a k_ast_fused workgroup
+#ifndef GAAST_INTERP_BUDGET_KB
+#define GAAST_INTERP_BUDGET_KB 144   /* (build switch for A/B runs) */
+#endif
+constexpr size_t kInterpLdsBytes = size_t(GAAST_INTERP_BUDGET_KB) * 1024;   // slabs of the 64 items of a k_ast_fused workgroup
 constexpr uint64_t kMaxListEntries = uint64_t(1) << 27;
 
 struct Plan {

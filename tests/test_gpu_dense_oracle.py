@@ -503,13 +503,13 @@ def test_n8_parity_pure_products_run_in_cl7_on_the_matrix_cores(lpar, rpar, metr
            batch=21, seed=780, right_grades=grades[rpar], label_has=f"{lpar} x {rpar} in Cl(7)")
 
 
-@pytest.mark.parametrize("n,metric", [(9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (11, [1.0] * 11), (12, [1.0] * 4 + [-1.0] * 8)])
+@pytest.mark.parametrize("n,metric", [(8, [1.0] * 8), (9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (11, [1.0] * 11), (12, [1.0] * 4 + [-1.0] * 8)])
 def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
     """(R X ~R).g(1), the rotor sandwich applied to a vector (README.md:62-67; eval.rs:61-86 with the cached R X), where the program
     no longer fits a fused small-program kernel: both products are lists (n 2^(n-1) entries each) and run in ONE
     k_product_ell_chain launch with the mid row R X in LDS -- reference order and roundings, so the result equals the oracle's
     and the two-launch plan's (GAAST_FLAG_DEBUG_NO_CHAIN) bit for bit.  The batch is not a multiple of the items a workgroup
-    stages."""
+    stages.  n = 8 would still fit the LDS interpreter (one launch as well): the chain kernel is preferred (11 % faster)."""
     even = EVEN(n)
     build = lambda B: (lambda r, x: (r * x * r.rev()).g(1))(B.input(0, even, n), B.input(1, [1], n))
     batch = 37 if n < 11 else 11 if n == 11 else 5
@@ -522,7 +522,7 @@ def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
     assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and "k_product_ell_chain<double>" in spec.launches()[0], spec.launches()
     assert np.array_equal(got, want)
     two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN)
-    assert len(spec2.launches()) == 2 and np.array_equal(two, want), spec2.launches()
+    assert len(spec2.launches()) == (2 if n > 8 else 1) and np.array_equal(two, want), spec2.launches()    # (n = 8 without the chain: the interpreter)
 
 
 @pytest.mark.parametrize("dtype", [ga.F64, ga.F32])

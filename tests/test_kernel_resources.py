@@ -72,6 +72,7 @@ def test_spills_stay_out_of_the_hot_kernels(kernels):
     ("k_gp_mfma16x4<float, false, 8, 2, false, false>", 6),       # BASELINE configs[1]
     ("k_gp_mfma16x4<double, false, 12, 2, false, false>", 4),     # r12d: 16 waves per item, one item per CU
     ("k_gp_spinor12s<5, true>", 2),
+    ("k_gp_mfma7<float, 2, false, false>", 8), ("k_gp_mfma7<double, 2, false, false>", 6),   # one wave per item: the waves of a SIMD are its latency hiding
 ])
 def test_hot_kernels_keep_their_occupancy(kernels, prefix, waves):
     for name, k in _find(kernels, prefix).items():
