@@ -1582,6 +1582,49 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
         }
     }
 
+    // CHAINED, register-prefetch path: when the list is R X at n = 8 -- 128 rows of 8 terms, +-1 coefficients -- a lane keeps the
+    // words of its two rows (and the rows' image words) in registers for all its items: list_eval_rows re-reads them from L1 per
+    // item, 18 vector-memory instructions per item and wave beside the two that move data (sand8: 1.43 -> 1.13 ms per 1 M items at
+    // 144 instead of 96 registers; an LDS copy of the words instead: 1.25 ms, and at n = 9, 10 -- where 52 registers more would
+    // spill -- the LDS copy LOSES 20 % to the workgroups it displaces).  Same terms, same order, same four-term grouping as
+    // list_eval_rows: the same bits.
+    const bool list_cached = CHAINED && FAST && p.pre_width == 8 && p.pre_rows == 2 * THREADS && p.pre_row_scale == nullptr;
+    uint32_t ce[2][8], crow[2] = {0, 0};
+    if constexpr (CHAINED && FAST) {
+        if (list_cached) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                crow[rr] = p.pre_row_map[tid + rr * THREADS];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ce[rr][k] = p.pre_entries[k * (2 * THREADS) + tid + rr * THREADS];
+            }
+        }
+    }
+    auto cached_list = [&]() {
+        const char* l = reinterpret_cast<const char*>(smem + p.pre_scratch);
+        const char* r = l + size_t(p.pre_left_len) * sizeof(T);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            T acc = T(0);
+#pragma unroll
+            for (int k0 = 0; k0 < 8; k0 += 4) {
+                T prod[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t e = ce[rr][k0 + k];
+                    prod[k] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
+                                               *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
+                                           e & 0x80000000u);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = acc + prod[k];
+            }
+            const uint32_t pos = (crow[rr] >> 16) & 0x7fffu;
+            const T val = list_flip<T>(acc, crow[rr] & 0x80000000u);
+            smem[A_EL + pos] = val;
+            smem[A_EL + pos + NEG_A_EL] = -val;
+        }
+    };
     auto one_item = [&](int64_t item, Pf& f) {
         // ---- both operands into their +/- images ----
         if (FAST) {
@@ -1620,7 +1663,8 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
                 fetch(nn < p.batch ? nn : item, f);
             }
             if constexpr (CHAINED) {
-                list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, NEG_A_EL);   // +A and -A at once
+                if (list_cached) cached_list();
+                else list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, NEG_A_EL);   // +A and -A at once
                 lds_barrier<THREADS>();
             }
         } else {

@@ -382,6 +382,24 @@ int main() {
             lower(e, n, n == 9 ? m63 : euclid, GAAST_F64, GAAST_FLAG_DEBUG_NO_CHAIN, what, "product_ell");   // rows of n entries, +-1: the [term][row] form
         }
     }
+    {   // list chains: (R X ~R).g(1) -- two lists, one step (k_product_ell_chain); n = 8 would also fit the LDS interpreter
+        for (int n : {8, 9, 10, 12}) {
+            uint64_t even = 0;
+            for (int k = 0; k <= n; k += 2) even |= uint64_t(1) << k;
+            gaast_expr_t r = gaast_expr_input(0, even, n), x = gaast_expr_input(1, 0x2, n), b = gaast_expr_input(2, even, n);
+            gaast_expr_t e = gaast_expr_g(gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC), 1);
+            char what[64];
+            std::snprintf(what, sizeof what, "projected sandwich n=%d: list chain", n);
+            lower(e, n, euclid, GAAST_F64, 0, what, "product_ell[");
+            lower(e, n, euclid, GAAST_F64, 0, what, " <- product_ell[");
+            std::snprintf(what, sizeof what, "projected sandwich n=%d: two lists", n);
+            lower(e, n, euclid, GAAST_F64, GAAST_FLAG_DEBUG_NO_CHAIN, what, n == 8 ? "ast_" : "product_ell[");
+            if (n == 9) {   // the mid row as the RIGHT operand of the second list, whose other operand is a third input
+                gaast_expr_t e2 = gaast_expr_g(gaast_expr_product(b, gaast_expr_product(x, gaast_expr_rev(r), GAAST_PROD_GEOMETRIC), GAAST_PROD_GEOMETRIC), 1);
+                lower(e2, n, euclid, GAAST_F32, 0, "b (x ~r) projected: mid row on the right", " <- product_ell[");
+            }
+        }
+    }
     for (gaast_expr_t h : handles) gaast_expr_release(h);
     if (failures) {
         std::printf("%d failures\n", failures);

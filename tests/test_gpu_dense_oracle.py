@@ -332,7 +332,8 @@ def test_parity_pure_with_a_general_metric_and_partial_grades():
            right_grades=EVEN(10), label_has="even x even in Cl(9)")
 
 
-@pytest.mark.parametrize("n,metric", [(8, [1.0] * 8), (9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (9, [2.0, 1.0, -0.5, 1.0, 1.0, 3.0, -1.0, 1.0, 0.25])])
+@pytest.mark.parametrize("n,metric", [(8, [1.0] * 8), (9, [1.0] * 6 + [-1.0] * 3), (10, [1.0] * 10), (9, [2.0, 1.0, -0.5, 1.0, 1.0, 3.0, -1.0, 1.0, 0.25]),
+                                      (8, [1.0, 1.0, 1.0, 0.0, 1.0, -1.0, 1.0, 1.0])])   # (a null vector: rows of different lengths -- the list stays CSR, not in registers)
 def test_rotor_sandwich_beyond_the_fused_slab_is_one_launch(n, metric):
     """BASELINE configs[4]'s pipeline R X ~R (eval.rs:61-86 with the cached operand R X, README.md:62-67) where it no longer fits
     a fused small-program kernel: the sparse product R X (n 2^(n-1) entries) is evaluated in the LDS staging of the dense
