@@ -1252,6 +1252,54 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
         if (int64_t(blockIdx.x) < p.batch) fetch(blockIdx.x);
     }
 
+    // CHAINED, register-prefetch path: when the list is R X of the sandwich -- four rows of (n padded to) 12 terms per thread, +-1
+    // coefficients: sand9 (this kernel at n = 8) -- a thread keeps the words of its rows and the rows' image words in registers for all its items
+    // (list_eval_rows re-reads them from L1 per item: 52 vector-memory instructions per item and wave).  The words stay PACKED in
+    // their registers (each is made opaque inside the item loop: hoisted, their decoded halves would triple the registers and
+    // spill).  Same terms, same order, same four-term grouping: the same bits.
+    constexpr bool LIST_CACHE = CHAINED && FAST && NDIM == 8;   // (n = 9: the 52 registers spill)
+    const bool list_cached = LIST_CACHE && p.pre_width == 12 && p.pre_rows == 4 * THREADS && p.pre_row_scale == nullptr;
+    uint32_t ce[LIST_CACHE ? 4 : 1][LIST_CACHE ? 12 : 1], crow[4] = {0, 0, 0, 0};
+    if constexpr (LIST_CACHE) {
+        if (list_cached) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                crow[rr] = p.pre_row_map[tid + rr * THREADS];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) ce[rr][t] = p.pre_entries[t * (4 * THREADS) + tid + rr * THREADS];
+            }
+        }
+    }
+    auto cached_list = [&]() {
+        if constexpr (LIST_CACHE) {
+            const char* l = reinterpret_cast<const char*>(smem + p.pre_scratch);
+            const char* r = l + size_t(p.pre_left_len) * sizeof(T);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                T acc = T(0);
+#pragma unroll
+                for (int k0 = 0; k0 < 12; k0 += 4) {
+                    T prod[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        uint32_t e = ce[rr][k0 + t];
+                        asm volatile("" : "+v"(e));
+                        prod[t] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
+                                                   *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
+                                               e & 0x80000000u);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = acc + prod[t];
+                }
+                uint32_t w = crow[rr];
+                asm volatile("" : "+v"(w));
+                const uint32_t pos = (w >> 16) & 0x7fffu;
+                const T val = list_flip<T>(acc, w & 0x80000000u);
+                smem[A_EL + pos] = val;
+                smem[A_EL + pos + N + PAD_A] = -val;
+            }
+        }
+    };
     for (int64_t item = blockIdx.x; item < p.batch; item += gridDim.x) {
         // ---- both operands into their +/- images ----
         if (FAST) {
@@ -1295,7 +1343,8 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             // KNOWN number of loads and stores per item, and the wait at its top is a counted one
             fetch(item + gridDim.x < p.batch ? item + gridDim.x : item);
             if constexpr (CHAINED) {
-                list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, N + PAD_A);   // +A and -A at once
+                if (list_cached) cached_list();
+                else list_eval_rows<T, THREADS>(p, 1, smem + A_EL, item_stride, smem + p.pre_scratch, tid, N + PAD_A);   // +A and -A at once
                 lds_barrier<THREADS>();
             }
         } else {
@@ -1611,7 +1660,8 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
                 T prod[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t e = ce[rr][k0 + k];
+                    uint32_t e = ce[rr][k0 + k];
+                    asm volatile("" : "+v"(e));   // the word stays packed in its register (hoisted, its decoded halves cost 32 registers more)
                     prod[k] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
                                                *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
                                            e & 0x80000000u);
