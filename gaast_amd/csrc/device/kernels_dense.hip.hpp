@@ -1633,9 +1633,9 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
 
     // CHAINED, register-prefetch path: when the list is R X at n = 8 -- 128 rows of 8 terms, +-1 coefficients -- a lane keeps the
     // words of its two rows (and the rows' image words) in registers for all its items: list_eval_rows re-reads them from L1 per
-    // item, 18 vector-memory instructions per item and wave beside the two that move data (sand8: 1.43 -> 1.13 ms per 1 M items at
-    // 144 instead of 96 registers; an LDS copy of the words instead: 1.25 ms, and at n = 9, 10 -- where 52 registers more would
-    // spill -- the LDS copy LOSES 20 % to the workgroups it displaces).  Same terms, same order, same four-term grouping as
+    // item, 18 vector-memory instructions per item and wave beside the two that move data (sand8: 1.43 -> 1.07 ms per 1 M items at
+    // 112 instead of 96 registers; an LDS copy of the words instead: 1.25 ms, and at n = 10 -- where the registers would spill --
+    // the LDS copy LOSES 20 % to the workgroups it displaces).  Same terms, same order, same four-term grouping as
     // list_eval_rows: the same bits.
     const bool list_cached = CHAINED && FAST && p.pre_width == 8 && p.pre_rows == 2 * THREADS && p.pre_row_scale == nullptr;
     uint32_t ce[2][8], crow[2] = {0, 0};
