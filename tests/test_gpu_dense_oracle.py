@@ -238,9 +238,10 @@ def test_n14_sixteen_waves_per_item_against_a_sparse_left_operand():
         assert np.array_equal(got[i], want), i
 
 
-@pytest.mark.parametrize("n,dtype", [(8, ga.F32), (8, ga.F64), (10, ga.F64), (10, ga.F32)])
+@pytest.mark.parametrize("n,dtype", [(7, ga.F32), (7, ga.F64), (8, ga.F32), (8, ga.F64), (10, ga.F64), (10, ga.F32)])
 def test_negative_zero_operands_leave_no_trace(n, dtype):
-    """The FAST staging of k_gp_mfma16x4 does not apply the `0.0 + x` of the reference's operand copy (graded.rs:74): a -0.0
+    """The FAST staging of k_gp_mfma16x4 (and of k_gp_mfma7, whose u = 1 tile elements also take a sign flip AFTER the accumulation: each
+    component adds one unflipped element, so a zero sum still ends as +0.0) does not apply the `0.0 + x` of the reference's operand copy (graded.rs:74): a -0.0
     component can only contribute +-0 to sums that start from +0.0, so the results -- all-zero sums included -- must equal, BIT
     FOR BIT, those of the same rows with every -0.0 replaced by +0.0, and no result may be -0.0 where the reference has +0.0.
     Rows: random values with a third of the components set to -0.0, plus rows that are entirely +-0.0."""
