@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6     # datasheet (64 cycles per v_mfma_f64_16x16x4_f64 at 2.4 GHz); not in the local guide
 MEASURED_FP64_MFMA_TFLOPS = 74.3   # tools/microbench/mfma_f64_rate.hip on this pool (profiles/r03_microbench_mfma_f64_rate.txt)
+POWER_CAP_W, POWER_IDLE_W, POWER_W_PER_TFLOPS, POWER_W_PER_TBPS = 1400.0, 250.0, 7.2, 129.0   # measured, round 3 (DESIGN.md 4.1 "A power roofline")
 SIDE_CONFIGS = ("r8", "cl41", "r12d")   # the other single-GPU BASELINE configurations the default line also times
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 GATHER_WATCHDOG_S = 240     # the multi-GPU gather legs give up after this long (the throughput line is printed regardless)
@@ -312,6 +313,11 @@ def roofline_of(wl, workload, spec, batch, kernel_ms, in_len, out_len):
                         f"algorithmic HBM {ach_gb:.1f} GB/s = {ach_gb / PEAK_HBM_GBPS:.4f} of 8 TB/s"}
         if dtype != ga.F32:
             roof["frac_of_measured_peak"] = ach_tf / MEASURED_FP64_MFMA_TFLOPS
+        else:
+            # informational: the FP32 rate 1,400 W buy at this kernel's HBM bytes per flop (DESIGN.md 4.1 "A power roofline":
+            # 250 W + 7.2 W per TFLOP/s + 129 W per TB/s, from rocm-smi readings under load, profiles/r03_clocks_and_power_under_load.txt)
+            cap_tf = (POWER_CAP_W - POWER_IDLE_W) / (POWER_W_PER_TFLOPS + POWER_W_PER_TBPS * (bytes_item / flops_item))
+            roof["power_capped_frac_ceiling"] = min(1.0, cap_tf / peak_tf)
     else:
         roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
                 "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
