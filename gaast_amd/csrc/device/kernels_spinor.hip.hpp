@@ -9,6 +9,25 @@
 #endif
 
 namespace gaast {
+#ifndef GAAST_SPINOR_NT
+#define GAAST_SPINOR_NT 3   /* bit 0: nontemporal 16-byte result stores, bit 1: nontemporal 16-byte operand loads (A/B switch; both: +1-2 %) */
+#endif
+__device__ __forceinline__ float4 spinor_load4(const float* row, int idx) {
+    if constexpr ((GAAST_SPINOR_NT & 2) != 0) {
+        const float4v t = __builtin_nontemporal_load(reinterpret_cast<const float4v*>(row) + idx);
+        return make_float4(t[0], t[1], t[2], t[3]);
+    } else {
+        return reinterpret_cast<const float4*>(row)[idx];
+    }
+}
+__device__ __forceinline__ void spinor_store4(float* row, int idx, float a, float b, float c, float d) {
+    if constexpr ((GAAST_SPINOR_NT & 1) != 0) {
+        const float4v t = {a, b, c, d};
+        __builtin_nontemporal_store(t, reinterpret_cast<float4v*>(row) + idx);
+    } else {
+        reinterpret_cast<float4*>(row)[idx] = make_float4(a, b, c, d);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // OPT-IN fast path (GAAST_FLAG_SPINOR_GEMM): the geometric product of a non-degenerate algebra
@@ -180,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-                if (FAST || p.left_len == 4096 || 4 * tid + 1024 * u4 < p.left_len) x = reinterpret_cast<const float4*>(lrow)[tid + 256 * u4];
-                if (FAST || p.right_len == 4096 || 4 * tid + 1024 * u4 < p.right_len) y = reinterpret_cast<const float4*>(rrow)[tid + 256 * u4];
+                if (FAST || p.left_len == 4096 || 4 * tid + 1024 * u4 < p.left_len) x = spinor_load4(lrow, tid + 256 * u4);
+                if (FAST || p.right_len == 4096 || 4 * tid + 1024 * u4 < p.right_len) y = spinor_load4(rrow, tid + 256 * u4);
                 va[4 * u4 + 0] = x.x; va[4 * u4 + 1] = x.y; va[4 * u4 + 2] = x.z; va[4 * u4 + 3] = x.w;
                 vb[4 * u4 + 0] = y.x; vb[4 * u4 + 1] = y.y; vb[4 * u4 + 2] = y.z; vb[4 * u4 + 3] = y.w;
             }
@@ -430,8 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_spinor12s(SpinorArgs p) {
                     uint32_t w[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)size_t(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
-                    reinterpret_cast<float4*>(orow)[tid + 256 * u4] =
-                        make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+                    spinor_store4(orow, tid + 256 * u4, __uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
                 }
             } else {
 #pragma unroll
@@ -793,8 +811,8 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
 #pragma unroll
             for (int u4 = 0; u4 < EPL / 4; ++u4) {
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-                if (p.left_len == NE || 4 * lane + 256 * u4 < p.left_len) x = reinterpret_cast<const float4*>(lrow)[lane + 64 * u4];
-                if (p.right_len == NE || 4 * lane + 256 * u4 < p.right_len) y = reinterpret_cast<const float4*>(rrow)[lane + 64 * u4];
+                if (p.left_len == NE || 4 * lane + 256 * u4 < p.left_len) x = spinor_load4(lrow, lane + 64 * u4);
+                if (p.right_len == NE || 4 * lane + 256 * u4 < p.right_len) y = spinor_load4(rrow, lane + 64 * u4);
                 va[4 * u4 + 0] = x.x; va[4 * u4 + 1] = x.y; va[4 * u4 + 2] = x.z; va[4 * u4 + 3] = x.w;
                 vb[4 * u4 + 0] = y.x; vb[4 * u4 + 1] = y.y; vb[4 * u4 + 2] = y.z; vb[4 * u4 + 3] = y.w;
             }
@@ -1016,8 +1034,7 @@ __global__ __launch_bounds__(64) void k_gp_spinor_wave1(SpinorArgs p) {
                     uint32_t w[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = *(const lds_u32*)size_t(om[4 * u4 + c] & 0x3fffffu) ^ (om[4 * u4 + c] & 0x80000000u);
-                    reinterpret_cast<float4*>(orow)[lane + 64 * u4] =
-                        make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+                    spinor_store4(orow, lane + 64 * u4, __uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
                 }
             } else {
 #pragma unroll
