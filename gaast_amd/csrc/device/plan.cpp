@@ -1306,7 +1306,11 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
                     for (int j = 0; j < 8; ++j) src += "      VT c" + std::to_string(j) + ";\n";
                     src += std::string("      if ((lane & 7) < ") + std::to_string(cpl) + ") {\n";
                     for (int j = 0; j < 8; ++j)
+#if GAAST_JIT_NT & 2
+                        src += "        c" + std::to_string(j) + " = __builtin_nontemporal_load((const VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * s" + I + "));\n";
+#else
                         src += "        c" + std::to_string(j) + " = *(const VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * s" + I + ");\n";
+#endif
                     for (int j = 0; j < 8; ++j)
                         src += "        *(VT*)(buf + (" + std::to_string(8 * j) + " + (lane >> 3)) * " + std::to_string(line_plen) + " + (lane & 7) * " + std::to_string(epc) + ") = c" + std::to_string(j) + ";\n";
                     src += "      }\n      __syncthreads();\n      const T* r = buf + lane * " + std::to_string(line_plen) + ";\n";
@@ -1468,8 +1472,13 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
                     src += "      __syncthreads();\n      T* base = out + item0 * so + " + std::to_string(e0) + " + (lane & 7) * " + std::to_string(epc) + ";\n";
                     src += std::string("      if ((lane & 7) < ") + std::to_string(cpl) + ") {\n";
                     for (int j = 0; j < 8; ++j)
+#if GAAST_JIT_NT & 1
+                        src += "        __builtin_nontemporal_store(*(const VT*)(buf + (" + std::to_string(8 * j) + " + (lane >> 3)) * " + std::to_string(line_plen) + " + (lane & 7) * " +
+                               std::to_string(epc) + "), (VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * so));\n";
+#else
                         src += "        *(VT*)(base + (long long)(" + std::to_string(8 * j) + " + (lane >> 3)) * so) = *(const VT*)(buf + (" + std::to_string(8 * j) +
                                " + (lane >> 3)) * " + std::to_string(line_plen) + " + (lane & 7) * " + std::to_string(epc) + ");\n";
+#endif
                     src += "      }\n    }\n";
                 }
                 src += "  } else\n";
