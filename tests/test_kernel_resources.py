@@ -79,3 +79,24 @@ def test_hot_kernels_keep_their_occupancy(kernels, prefix, waves):
         regs = -(-k["vgpr"] // 8) * 8          # .vgpr_count is the unified total (arch + accumulation registers); granule: 8
         assert k["spill"] == 0, (name, k)
         assert regs * waves <= 512, (name, k, f"{regs} registers: fewer than {waves} waves per SIMD")
+
+
+def test_library_revision_matches_the_sources_it_was_built_from():
+    """gaast_hip_version() carries an md5 of everything that decides which kernel code runs (csrc/Makefile: KREV); PMC traffic figures are
+    keyed to it (profiles/traffic.json).  The string is compiled into runtime.o, which a change in plan.cpp alone once failed to rebuild:
+    the library must report the revision of the sources in the tree (default build switches)."""
+    import glob
+    import hashlib
+    import os
+    import gaast_amd
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaast_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(root, "device", "*.hip.hpp"))) + [os.path.join(root, "device", f) for f in
+                                                                              ("runtime.hip", "plan.cpp", "plan.hpp", "spinor_basis.hpp")]
+    h = hashlib.md5()
+    for f in files:
+        h.update(open(f, "rb").read())
+    h.update(b"\n")          # echo "$(KFLAGS)" with no switches
+    version = gaast_amd.lib().gaast_hip_version().decode()
+    if os.environ.get("GAAST_HIP_LIB"):
+        pytest.skip("an A/B build is selected")
+    assert version.endswith(h.hexdigest()[:12]), (version, h.hexdigest()[:12])
