@@ -122,6 +122,7 @@ struct Step {
     std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
     void* jit_module = nullptr;
     void* jit_function = nullptr;
+    std::vector<char> jit_code;   // the hiprtc code object jit_module was loaded from: kept until the module is unloaded
     // launch configuration, fixed once at gaast_hip_program_create (runtime.hip: prepare_step): kernel, block
     // size, dynamic LDS, persistent-grid size.  ELL products pick kern[log2(items per pass)] by batch.
     const void* kern[4] = {nullptr, nullptr, nullptr, nullptr};

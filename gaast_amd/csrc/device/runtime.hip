@@ -30,10 +30,12 @@ bool g_init = false;
 int g_device = -1;
 hipStream_t g_stream = nullptr;
 int g_num_cu = 256;
+bool g_chain_too_big = false;      // program_create: a chained step went beyond the LDS the plan builder had budgeted
 size_t g_max_lds = 160 * 1024;
 Comm g_comm;                       // the gather communicator (gaast_hip_comm_init), if any
 std::vector<hipEvent_t> g_events;  // chunk-done events of gaast_hip_eval_gather, created on demand
 hipEvent_t g_comm_done = nullptr;
+int64_t* g_comm_flag = nullptr;    // device word of gaast_hip_eval_gather's collective error flag
 
 int set_err(int status, const std::string& msg) {
     g_err = msg;
@@ -106,6 +108,7 @@ void release_plan_resources(Plan& plan) {
         if (s.jit_module) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module));
         s.jit_module = nullptr;
         s.jit_function = nullptr;
+        std::vector<char>().swap(s.jit_code);   // only after the unload: the image outlives the module built from it
     }
 }
 
@@ -222,7 +225,10 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         if (s.list_chain) {
             // two lists in one launch, the mid row in LDS (plan.cpp: chain_list_into_list): IPB items per workgroup
             s.lds = size_t(s.chain_ent2_lds) + size_t(s.chain_item_stride) * size_t(s.chain_ipb) * sizeof(T);
-            if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "list chain does not fit in LDS (" + s.name + ")");
+            if (s.lds > g_max_lds) {
+                g_chain_too_big = true;
+                return set_err(GAAST_ERR_UNIMPLEMENTED, "list chain does not fit in LDS (" + s.name + ")");
+            }
             const int64_t pairs2 = int64_t(s.u32_b.size()) * s.chain_ipb;
             s.threads = int(std::min<int64_t>(512, std::max<int64_t>(256, (pairs2 + 63) / 64 * 64)));
             s.kern[0] = reinterpret_cast<const void*>(&k_product_ell_chain<T>);
@@ -659,17 +665,27 @@ bool jit_compile(Step& s, std::string* log) {
         return false;
     }
     size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(prog, code.data());
+    std::vector<char> code;
+    bool got = hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+    if (got) {
+        code.resize(cs);
+        got = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+    }
     hiprtcDestroyProgram(&prog);
+    if (!got) {
+        *log = "hiprtcGetCodeSize / hiprtcGetCode failed";
+        return false;
+    }
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
+    // HIP's header does not say that hipModuleLoadData copies the image: it stays alive, in the step, for as long as the
+    // module does (release_plan_resources frees it after hipModuleUnload).  std::move keeps code.data() where it is.
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
     if (hipModuleGetFunction(&fn, mod, "gaast_jit") != hipSuccess) {
         (void)hipModuleUnload(mod);
         return false;
     }
+    s.jit_code = std::move(code);
     s.jit_module = mod;
     s.jit_function = fn;
     return true;
@@ -698,6 +714,8 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     if (plan.has_explog) args.push_back(&dom);
     const unsigned threads = unsigned(s.jit_threads);
     const unsigned blocks = unsigned((batch + threads - 1) / threads);
+    // (the argument block -- args, ptrs, strides and the locals they point at -- only has to live until this call returns:
+    //  hipModuleLaunchKernel copies the kernel arguments into the dispatch packet's kernarg segment at call time)
     HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,
                                   args.data(), nullptr));
     (void)plan;
@@ -788,6 +806,8 @@ int gaast_hip_shutdown(void) {
         g_events.clear();
         if (g_comm_done) (void)hipEventDestroy(g_comm_done);
         g_comm_done = nullptr;
+        if (g_comm_flag) (void)hipFree(g_comm_flag);
+        g_comm_flag = nullptr;
     }
     g_init = false;
     return GAAST_OK;
@@ -805,9 +825,25 @@ int gaast_hip_synchronize(void) {
     return GAAST_OK;
 }
 
+static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program_t* out);
+
 int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t* out) {
     if (!desc || !out) return set_err(GAAST_ERR_INVALID_ARGUMENT, "null argument");
     if (int st = ensure_init()) return st;
+    g_chain_too_big = false;
+    const int st = program_create_impl(desc, out);
+    // The plan builder sizes a chain's LDS with its own estimate of the kernel's images; prepare_step checks the real figure
+    // against the device.  On a mismatch the unchained plan of the same program still runs: rebuild without chains
+    // (as the hiprtc-failure fallback does) instead of refusing the program.
+    if (st == GAAST_ERR_UNIMPLEMENTED && g_chain_too_big && !(desc->flags & GAAST_FLAG_DEBUG_NO_CHAIN)) {
+        gaast_program_desc d2 = *desc;
+        d2.flags |= GAAST_FLAG_DEBUG_NO_CHAIN;
+        return program_create_impl(&d2, out);
+    }
+    return st;
+}
+
+static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program_t* out) {
     auto prog = std::make_unique<gaast_hip_program_s>();  // its destructor releases whatever a failure leaves behind
     try {
         build_plan(*desc, prog->plan);
@@ -870,7 +906,10 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
             s.pre_scratch_off = (s.lds + 15) / 16 * 16;
             const size_t items = size_t(s.items_per_block > 0 ? s.items_per_block : 1);
             s.lds = s.pre_scratch_off + items * size_t(s.pre_left_len + s.pre_right_len + 1) * dtype_size(plan.dtype);   // + the zero pair
-            if (s.lds > g_max_lds) return set_err(GAAST_ERR_UNIMPLEMENTED, "chained product does not fit in LDS (" + s.name + ")");
+            if (s.lds > g_max_lds) {
+                g_chain_too_big = true;
+                return set_err(GAAST_ERR_UNIMPLEMENTED, "chained product does not fit in LDS (" + s.name + ")");
+            }
             for (int v = 0; v < 3; ++v)
                 if (s.kern[v])
                     if (int st = allow_lds(s.kern[v], s.lds)) return st;
@@ -958,7 +997,11 @@ int gaast_hip_program_create(const gaast_program_desc* desc, gaast_hip_program_t
 
 int gaast_hip_program_destroy(gaast_hip_program_t prog) {
     if (!prog) return GAAST_OK;
-    if (g_init) (void)hipSetDevice(g_device);
+    if (g_init) {
+        (void)hipSetDevice(g_device);
+        // launches of this program may still be in flight: a hiprtc module must not be unloaded (nor a table freed) under them
+        (void)hipStreamSynchronize(g_stream);
+    }
     delete prog;
     return GAAST_OK;
 }
@@ -1137,6 +1180,7 @@ int bind_eval(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs, int n_inpu
 // the launches of one evaluation over items [first, first + count) of the bound buffers
 int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, gaast_hip_mv_t out, int64_t first, int64_t count) {
     Plan& plan = prog->plan;
+    if (plan.flags & GAAST_FLAG_DEBUG_FAIL_EVAL) return set_err(GAAST_ERR_HIP, "injected evaluation failure (GAAST_FLAG_DEBUG_FAIL_EVAL)");
     if (count == 0) return GAAST_OK;
     const size_t sz = dtype_size(plan.dtype);
     auto shifted = [&](Bound b) {
@@ -1388,7 +1432,8 @@ int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs
     // chunk c is computed on the library stream; its rows leave on the communicator's stream while chunk c + 1 is
     // being computed.  Every rank walks all n_chunks steps (a rank with fewer items has empty chunks) so that
     // sends and receives pair up -- also after a local failure: the remaining transfers are still posted (of whatever
-    // the rows hold) so that no peer is left waiting in a receive, and the first error is returned afterwards.
+    // the rows hold) so that no peer is left waiting in a receive.  The failure is then made COLLECTIVE: every rank
+    // all-reduces an error flag and returns non-zero if any rank failed (the root must not hand out stale rows as GAAST_OK).
     int first_error = GAAST_OK;
     std::string first_msg;
     auto note = [&](int st) {
@@ -1410,7 +1455,23 @@ int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t* inputs
         note(gather_chunk(out, gathered, counts, root, n_chunks, c));
     }
     note(join_comm_stream());
+    // the collective error flag (sum over the ranks of "I failed"), on the communicator's stream behind the transfers
+    int64_t failed_ranks = first_error != GAAST_OK ? 1 : 0;
+    {
+        std::string err;
+        hipError_t e = g_comm_flag ? hipSuccess : hipMalloc(reinterpret_cast<void**>(&g_comm_flag), sizeof(int64_t));
+        if (e == hipSuccess) e = hipMemcpy(g_comm_flag, &failed_ranks, sizeof(failed_ranks), hipMemcpyHostToDevice);
+        int rc = 0;
+        if (e == hipSuccess) rc = comm_allreduce_sum_i64(g_comm, g_comm_flag, 1, &err);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(g_comm.stream);
+        if (e == hipSuccess && !rc) e = hipMemcpy(&failed_ranks, g_comm_flag, sizeof(failed_ranks), hipMemcpyDeviceToHost);
+        if (rc) note(rccl_err(err));
+        else if (e != hipSuccess) note(set_err(GAAST_ERR_HIP, std::string("gaast_hip_eval_gather: error flag: ") + hipGetErrorString(e)));
+    }
     if (first_error != GAAST_OK) return set_err(first_error, first_msg);
+    if (failed_ranks > 0)
+        return rccl_err("gaast_hip_eval_gather: another rank failed (" + std::to_string(failed_ranks) + " of " + std::to_string(g_comm.world) +
+                        "): the gathered rows are not valid");
     return GAAST_OK;
 }
 

@@ -143,6 +143,7 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_EXP_LOG 0x100u
 #define GAAST_FLAG_DEBUG_LDS_12K 0x400u /* hiprtc-specialised kernels: 12 KiB instead of 10 KiB of LDS per wave for the row transposition (A/B testing) */
 #define GAAST_FLAG_DEBUG_NO_CHAIN 0x800u /* a sparse product that only feeds a dense product stays a launch of its own (default: evaluated in the dense kernel's LDS staging; A/B testing) */
+#define GAAST_FLAG_DEBUG_FAIL_EVAL 0x1000u /* every evaluation of this program fails with GAAST_ERR_HIP before its first launch: exercises the failure path of gaast_hip_eval_gather on ONE rank */
 #define GAAST_FLAG_NO_COALESCE 0x200u  /* hiprtc-specialised kernels: every lane reads / writes its own row (no LDS-transposed coalesced row I/O; A/B testing) */
 
 typedef struct gaast_program_desc {
@@ -251,6 +252,13 @@ int gaast_hip_gather_rows(gaast_hip_mv_t local, gaast_hip_mv_t gathered, const i
  * Equivalent to gaast_hip_eval(prog, inputs, n_inputs, counts[rank], out) followed by
  * gaast_hip_gather_rows(out, gathered, counts, root).  `out` may be the rows of `gathered` that belong to the
  * root itself (same device memory): the local copy is then skipped.
+ * FAILURE IS COLLECTIVE: a rank whose evaluation fails after the argument checks (a launch error) still posts
+ * its transfers, so that no peer is left waiting in a receive, and before returning every rank all-reduces an
+ * error flag over the communicator: if ANY rank failed, EVERY rank returns non-zero (the failing rank its own
+ * status, the others GAAST_ERR_RCCL "another rank failed") and the contents of `gathered` are unspecified.  The
+ * flag exchange makes this entry point synchronous with the communicator's stream: when it returns GAAST_OK
+ * the gathered rows have arrived.  (Argument errors are detected before any transfer and are the caller's to
+ * keep consistent across ranks: the same counts / root / n_chunks everywhere.)
  */
 int gaast_hip_eval_gather(gaast_hip_program_t prog, const gaast_hip_mv_t *inputs, int n_inputs,
                           gaast_hip_mv_t out, gaast_hip_mv_t gathered, const int64_t *counts, int root,

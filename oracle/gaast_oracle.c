@@ -991,7 +991,7 @@ static void negate_grade(og_mv *m, int k, int *status) { /* graded.rs:61-65 */
     for (size_t i = 0; i < m->len[k]; ++i) s[i] = -s[i];
 }
 
-static void add_grades_from(og_mv *self, const og_mv *input, og_gradeset grades, int *status) {
+static void add_grades_from(og_mv *self, const og_mv *input, og_gradeset grades, int *status, int f32) {
     /* graded.rs:67-78 */
     og_gradeset igs = mv_grade_set(input);
     int ks[OG_MAX_GRADE];
@@ -1003,6 +1003,14 @@ static void add_grades_from(og_mv *self, const og_mv *input, og_gradeset grades,
             double *res = grade_slice_mut(self, (size_t)k, status);
             if (!res) return;
             size_t len = self->len[k] < input->len[k] ? self->len[k] : input->len[k]; /* zip */
+            if (f32) { /* OG_EVAL_F32: the same statement on binary32 values (the input is rounded as the upload rounds it) */
+                for (size_t i = 0; i < len; ++i) {
+                    const float r = (float)res[i], x = (float)in[i];
+                    const float sum = r + x;
+                    res[i] = (double)sum;
+                }
+                continue;
+            }
             for (size_t i = 0; i < len; ++i) res[i] = res[i] + in[i];
         }
     }
@@ -1163,7 +1171,7 @@ static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /*
     int nk;
     switch (this_->kind) {
     case OG_N_GRADED_OBJ: /* eval.rs:45-50 */
-        add_grades_from(c->slot[res_id], this_->input, this_->minimal, &c->status);
+        add_grades_from(c->slot[res_id], this_->input, this_->minimal, &c->status, c->mode & OG_EVAL_F32);
         return;
     case OG_N_ADDITION: /* eval.rs:51-54 */
         add_to_res(s, res_id, this_->child0, c);
@@ -1204,6 +1212,15 @@ static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /*
             double *rs = grade_slice_mut(res, mul->result_grade, &c->status);
             if (!rs) return;
             double *val_result = &rs[mul->result_index];
+            if (c->mode & OG_EVAL_F32) { /* eval.rs:82 on binary32: (l * r) rounded, * coeff rounded, += rounded */
+                const float l = (float)val_left, r = (float)val_right, cf = (float)mul->coeff;
+                float prod = l * r;
+                prod = prod * cf;
+                const float acc = (float)*val_result;
+                const float sum = acc + prod;
+                *val_result = (double)sum;
+                continue;
+            }
             *val_result += val_left * val_right * mul->coeff;
         }
         return;
@@ -1237,6 +1254,12 @@ static void add_to_res(const og_spec *s, int res_id, int this_id, cache *c) { /*
         if (c->status != OG_OK) return;
         double *sl = grade_slice_mut(c->slot[res_id], 0, &c->status);
         if (!sl) return;
+        if (c->mode & OG_EVAL_F32) { /* correctly rounded binary32 division / square root */
+            const float x = (float)sl[0];
+            const float y = this_->kind == OG_N_SCALAR_INVERSION ? 1.0f / x : sqrtf(x);
+            sl[0] = (double)y;
+            return;
+        }
         sl[0] = this_->kind == OG_N_SCALAR_INVERSION ? 1.0 / sl[0] : sqrt(sl[0]);
         return;
     }
@@ -1349,6 +1372,10 @@ size_t og_pack_root_product(const og_spec *s, og_packed_mul **out, size_t *left_
         p[e].right = (uint32_t)(row_offset_of(r->minimal, dim, m->right_grade) + m->right_index);
         p[e].out = (uint32_t)(row_offset_of(root->minimal, dim, m->result_grade) + m->result_index);
         p[e].coeff = (float)m->coeff;
+        if ((double)p[e].coeff != m->coeff) { /* a general diagonal metric: the 16-byte entry would compute another product */
+            free(p);
+            return 0;
+        }
     }
     *out = p;
     *left_len = row_len_of(l->minimal, dim);
@@ -1387,18 +1414,21 @@ double og_packed_eval_batch(const og_packed_mul *muls, size_t n, const double *l
     if ((int64_t)threads > batch) threads = (int)(batch > 0 ? batch : 1);
     packed_job *jobs = (packed_job *)malloc(sizeof(packed_job) * (size_t)threads);
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    char *started = (char *)calloc((size_t)threads, 1);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int64_t per = (batch + threads - 1) / threads;
     for (int t = 0; t < threads; ++t) {
         jobs[t] = (packed_job){muls, n, left_len, right_len, out_len, left, right, out, t * per, (t + 1) * per < batch ? (t + 1) * per : batch};
-        if (threads == 1) packed_worker(&jobs[t]);
-        else pthread_create(&tid[t], NULL, packed_worker, &jobs[t]);
+        /* a thread that cannot be started does not silently skip its items (the throughput would read too high): inline */
+        if (threads > 1 && pthread_create(&tid[t], NULL, packed_worker, &jobs[t]) == 0) started[t] = 1;
+        else packed_worker(&jobs[t]);
     }
-    if (threads > 1)
-        for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    for (int t = 0; t < threads; ++t)
+        if (started[t]) pthread_join(tid[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(jobs);
     free(tid);
+    free(started);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

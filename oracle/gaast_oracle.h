@@ -168,7 +168,13 @@ enum { OG_EVAL_RELEASE = 0, /* k*(k-1)/2 wraps for k == 0: grade 0 untouched (SU
        /* EXTENSION, bit flag, "no reference behaviour, parity unpinned": evaluate Exponential / Logarithm (todo!() in
         * eval.rs:112-113) with the semantics the reference's grade rules imply (grade_set.rs:181-197), see the
         * comment above ext_exp_log() in gaast_oracle.c.  Without the flag these arms panic like the reference. */
-       OG_EVAL_EXT_EXPLOG = 2 };
+       OG_EVAL_EXT_EXPLOG = 2,
+       /* F32 MODE, bit flag -- an extension of the BUILD, not of the reference (which is f64-only, graded.rs:46): the same
+        * statements in the same order with EVERY operand read and every operation's result rounded to IEEE binary32, so that
+        * the f32 exact kernels (an extension too, SURVEY 8b "data-type note") are checked bit for bit like the f64 ones.
+        * Values travel in the double slabs; every one of them is exactly a float.  Pinned by the reference's four eval
+        * known-answer tests (exactly representable in f32).  exp / log keep their f64 statements (not combined with EXT). */
+       OG_EVAL_F32 = 4 };
 /* tolerance of the extension's domain check: a k-vector B is accepted when |<B^2>_{not 0}|^2 <= 2^-40 (sum B_i^2)^2 */
 #define OG_EXPLOG_DOMAIN_TOL2 9.094947017729282e-13
 int og_eval(const og_spec *s, int mode, og_mv **out);
@@ -198,7 +204,7 @@ void og_product_loop(const og_comp_mul *muls, size_t n, double *const *left, dou
  * infrastructure only (never a checker: the literal og_eval above is). */
 typedef struct og_packed_mul {
     uint32_t left, right, out; /* offsets in the operands' / result's graded rows (grades ascending, concatenated) */
-    float coeff;               /* +-1 / 0 / metric products: exact in f32 for the benchmarked +-1 metrics */
+    float coeff;               /* +-1 / 0 / metric products that are exact in f32; og_pack_root_product REFUSES (returns 0) a list with any other coefficient */
 } og_packed_mul;
 /* packs the comp-mul list of the ROOT product of `s` (both operands GradedObj leaves); returns the entry count, 0 on
  * failure; *out is malloc'ed (free with og_packed_free) */

@@ -20,6 +20,7 @@ OG_OK = 0
 PANICS = {1: "MISSING_GRADE", 2: "TODO", 3: "ASSERT", 4: "OVERFLOW", 5: "BAD_ARG"}
 SEL_GEOMETRIC, SEL_OUTER, SEL_INNER, SEL_LCONTRACT, SEL_RCONTRACT = range(5)
 EVAL_RELEASE, EVAL_DEBUG = 0, 1
+EVAL_F32 = 4          # bit flag: every operand and result rounded to binary32 (checks the f32 exact kernels bit for bit)
 EVAL_EXT_EXPLOG = 2   # bit flag: the exp / log EXTENSION (no reference behaviour, parity unpinned), see gaast_oracle.c
 PANIC_DOMAIN = 5
 NODE_KINDS = ["GradedObj", "Addition", "Product", "Negation", "Exponential", "Logarithm",

@@ -8,7 +8,11 @@
  * in.bin : batch x 16 doubles (R: grades 0, 2, 4 concatenated per item) then batch x 5 doubles (X: grade 1)
  * out.bin: batch x 16 doubles (root: grades 1, 3, 5)
  * gather : go through the multi-GPU entry points with a one-rank communicator (gaast_hip_eval_gather, 4 chunks)
+ * hiprtc_first : the ORDER that preceded round 3's two aborts, made deterministic: this process compiles, loads and launches
+ *          three kernels through hiprtc (dlopen'd, no library of ours involved) BEFORE gaast_hip_init, then evaluates the
+ *          unfused plan (GAAST_FLAG_NO_FUSION: statically compiled kernels only -- the first launches out of the fat binary)
  * tests/test_gpu_abi_c_host.py compares out.bin with the oracle, bit for bit. */
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,18 +29,87 @@
         }                                                                                     \
     } while (0)
 
+/* hiprtc and the HIP module API through dlopen (plain C: no HIP header needed for a handful of entry points) */
+static int use_hiprtc_before_the_library(void) {
+    void *rtc = dlopen("libhiprtc.so", RTLD_NOW | RTLD_GLOBAL), *hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!rtc || !hip) {
+        fprintf(stderr, "dlopen: %s\n", dlerror());
+        return 1;
+    }
+    typedef int (*create_t)(void **, const char *, const char *, int, const char **, const char **);
+    typedef int (*compile_t)(void *, int, const char **);
+    typedef int (*size_t_fn)(void *, size_t *);
+    typedef int (*code_t)(void *, char *);
+    typedef int (*destroy_t)(void **);
+    typedef int (*load_t)(void **, const void *);
+    typedef int (*getfn_t)(void **, void *, const char *);
+    typedef int (*launch_t)(void *, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, void *, void **, void **);
+    typedef int (*malloc_t)(void **, size_t);
+    typedef int (*memcpy_t)(void *, const void *, size_t, int);
+    typedef int (*sync_t)(void);
+    typedef int (*unload_t)(void *);
+    typedef int (*free_t)(void *);
+    create_t create = (create_t)dlsym(rtc, "hiprtcCreateProgram");
+    compile_t compile = (compile_t)dlsym(rtc, "hiprtcCompileProgram");
+    size_t_fn code_size = (size_t_fn)dlsym(rtc, "hiprtcGetCodeSize");
+    code_t get_code = (code_t)dlsym(rtc, "hiprtcGetCode");
+    destroy_t destroy = (destroy_t)dlsym(rtc, "hiprtcDestroyProgram");
+    load_t load = (load_t)dlsym(hip, "hipModuleLoadData");
+    getfn_t getfn = (getfn_t)dlsym(hip, "hipModuleGetFunction");
+    launch_t launch = (launch_t)dlsym(hip, "hipModuleLaunchKernel");
+    malloc_t dmalloc = (malloc_t)dlsym(hip, "hipMalloc");
+    memcpy_t dmemcpy = (memcpy_t)dlsym(hip, "hipMemcpy");
+    sync_t dsync = (sync_t)dlsym(hip, "hipDeviceSynchronize");
+    unload_t unload = (unload_t)dlsym(hip, "hipModuleUnload");
+    free_t dfree = (free_t)dlsym(hip, "hipFree");
+    if (!create || !compile || !code_size || !get_code || !destroy || !load || !getfn || !launch || !dmalloc || !dmemcpy || !dsync || !unload || !dfree) return 1;
+    int *d = NULL;
+    if (dmalloc((void **)&d, 3 * sizeof(int))) return 1;
+    for (int k = 0; k < 3; ++k) {
+        char src[256];
+        snprintf(src, sizeof src, "extern \"C\" __global__ void probe%d(int* p) { if (threadIdx.x == 0) p[%d] = %d; }\n", k, k, 100 + k);
+        void *prog = NULL;
+        const char *opts[] = {"--offload-arch=gfx950"};
+        if (create(&prog, src, "probe.hip", 0, NULL, NULL) || compile(prog, 1, opts)) return 1;
+        size_t cs = 0;
+        if (code_size(prog, &cs) || !cs) return 1;
+        char *image = malloc(cs);
+        if (get_code(prog, image) || destroy(&prog)) return 1;
+        void *mod = NULL, *fn = NULL;
+        char name[16];
+        snprintf(name, sizeof name, "probe%d", k);
+        if (load(&mod, image) || getfn(&fn, mod, name)) return 1;
+        void *arg = d, *args[1];
+        args[0] = &arg;
+        if (launch(fn, 1, 1, 1, 64, 1, 1, 0, NULL, args, NULL) || dsync()) return 1;
+        if (unload(mod)) return 1;
+        free(image);
+    }
+    int got[3] = {0, 0, 0};
+    if (dmemcpy(got, d, sizeof got, 2 /* hipMemcpyDeviceToHost */) || dfree(d)) return 1;
+    if (got[0] != 100 || got[1] != 101 || got[2] != 102) return 1;
+    printf("hiprtc first: three kernels compiled, loaded and run before gaast_hip_init\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: abi_host in.bin out.bin batch [gather]\n");
+        fprintf(stderr, "usage: abi_host in.bin out.bin batch [gather | hiprtc_first]\n");
         return 2;
     }
     const int64_t batch = atoll(argv[3]);
     const int use_gather = argc > 4 && strcmp(argv[4], "gather") == 0;
+    const int hiprtc_first = argc > 4 && strcmp(argv[4], "hiprtc_first") == 0;
+    if (hiprtc_first && use_hiprtc_before_the_library()) {
+        fprintf(stderr, "the hiprtc preamble failed\n");
+        return 1;
+    }
     const int n = CFG5_N;
     const uint64_t EVEN = CFG5_EVEN, VEC = CFG5_VEC, ODD = CFG5_ODD; /* grades {0,2,4}, {1}, {1,3,5} */
     static cfg5_program cfg;
     cfg5_fill(&cfg);
 #define desc cfg.desc
+    if (hiprtc_first) desc.flags |= GAAST_FLAG_NO_FUSION;   /* statically compiled kernels only */
 
     const int dev = 0;
     TRY(gaast_hip_init(&dev, 1));

@@ -96,6 +96,9 @@ int main(int argc, char **argv) {
         return 1;
     }
 
+    /* negative test: ONE rank's evaluation fails (GAAST_TEST_FAIL_EVAL_RANK = that rank); every rank must be told */
+    const char *fail_rank = getenv("GAAST_TEST_FAIL_EVAL_RANK");
+    if (fail_rank && atoi(fail_rank) == rank) cfg.desc.flags |= GAAST_FLAG_DEBUG_FAIL_EVAL;
     gaast_hip_program_t prog = NULL;
     TRY(gaast_hip_program_create(&cfg.desc, &prog));
 
@@ -132,6 +135,14 @@ int main(int argc, char **argv) {
     /* negative test: the root believes the last rank sends one row less than it does -> the transport must report
      * that a receive met a send of another size (tests/test_gpu_multirank_gather.py) */
     if (getenv("GAAST_TEST_ROOT_MISCOUNT") && rank == root && world > 1) counts[root == world - 1 ? 0 : world - 1] -= 1;
+    if (fail_rank) {
+        /* the failure of one rank's evaluation is COLLECTIVE (include/gaast_hip.h): every rank returns non-zero, the
+         * failing rank its own status, the others GAAST_ERR_RCCL; exit code 42 = "reported as specified" */
+        const int st = gaast_hip_eval_gather(prog, ins, 2, mOut, mAll, counts, root, n_chunks);
+        const int want = atoi(fail_rank) == rank ? GAAST_ERR_HIP : GAAST_ERR_RCCL;
+        fprintf(stderr, "rank %d: injected failure on rank %s -> status %d (%s)\n", rank, fail_rank, st, gaast_hip_last_error());
+        return st == want ? 42 : 1;
+    }
     /* twice: the second pass runs over warm buffers and must deliver the same rows */
     for (int pass = 0; pass < 2; ++pass) TRY(gaast_hip_eval_gather(prog, ins, 2, mOut, mAll, counts, root, n_chunks));
     TRY(gaast_hip_gather_rows(mOut, mAll2, counts, root));   /* the blocking form, into a second buffer */

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(ROOT, "gaast_amd", "lib")
 def _build(tmp_path):
     exe = tmp_path / "abi_host"
     subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "tests", "cpp", "abi_host.c"), "-L", LIBDIR, "-lgaast_hip",
+                    os.path.join(ROOT, "tests", "cpp", "abi_host.c"), "-L", LIBDIR, "-lgaast_hip", "-ldl",
                     "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     return exe
 
@@ -29,7 +29,7 @@ def test_c_host_compiles_and_links_against_the_header_and_library(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,batch", [("", 1), ("", 777), ("gather", 777), ("gather", 3)])
+@pytest.mark.parametrize("mode,batch", [("", 1), ("", 777), ("gather", 777), ("gather", 3), ("hiprtc_first", 777)])
 def test_c_host_evaluates_config_5_bit_exact(tmp_path, mode, batch):
     exe = _build(tmp_path)
     rng = np.random.default_rng(55)
@@ -40,10 +40,16 @@ def test_c_host_evaluates_config_5_bit_exact(tmp_path, mode, batch):
     run = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(batch)] + ([mode] if mode else []),
                          capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
-    assert run.stdout.strip().endswith("OK") and "launch 0: ast_" in run.stdout
+    assert run.stdout.strip().endswith("OK")
+    if mode == "hiprtc_first":
+        # the order that preceded round 3's two aborts: hiprtc used by the process BEFORE gaast_hip_init, then
+        # the first launches out of the library's own code object (the unfused plan runs statically compiled kernels only)
+        assert "hiprtc first" in run.stdout and "ast_" not in run.stdout and "k_product_" in run.stdout
+    else:
+        assert "launch 0: ast_" in run.stdout
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float64).reshape(batch, 16)
     build = lambda B: (lambda r, x: r * x * r.rev())(B.input(0, [0, 2, 4], 5), B.input(1, [1], 5))
     want, mask = oracle_eval_batch(build, [1.0, 1.0, 1.0, 1.0, -1.0], rows, batch)
     assert mask == 0x2A and np.array_equal(got, want)
-    if mode:
+    if mode == "gather":
         assert "1 rank(s) counted" in run.stdout

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import gaast_amd as ga
+from oracle import pyoracle as ogm
 from helpers import abs_terms_bound, bits_to_row, full_grades, hip_eval_batch, oracle_eval_batch, row_to_bits, rows_of
 
 pytestmark = pytest.mark.gpu
@@ -159,7 +160,9 @@ def test_random_dense_products_on_the_default_path(chunk):
         where = (n, dtype, metric, lg, rg, og_sel, batch, shared, spec.launches())
         assert mask == wmask, where
         if not any("product_dense" in l for l in spec.launches()):
-            assert np.array_equal(got.astype(np.float64), want) or dtype == ga.F32, where   # exact list kernels
+            # exact list kernels: bit for bit, in f32 against the oracle's F32 mode (same statements on binary32 values)
+            exact = want if dtype == ga.F64 else oracle_eval_batch(build, metric, rows64, batch, mode=ogm.EVAL_F32)[0]
+            assert np.array_equal(got.astype(np.float64), exact), where
             continue
         dense_cases += 1
         og = [k for k in range(n + 1) if (wmask >> k) & 1]
@@ -531,7 +534,7 @@ def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
 def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtype):
     """a (x b) with the mid row as the RIGHT operand of the second list; (a x) b with three different inputs (the second list stages a
     row of its own); the second list adding into a buffer another product wrote (beta = 1); in both value types, bit-exact against the
-    oracle (f64) / the two-launch plan (f32: the oracle computes in f64)"""
+    oracle (f64: the reference's arithmetic; f32: the oracle's F32 mode, the same statements on binary32 values) AND the two-launch plan"""
     n, batch = 9, 21
     even = EVEN(n)
     npdt = np.float32 if dtype == ga.F32 else np.float64
@@ -549,6 +552,6 @@ def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtyp
         if not any("ast_fused" in l for l in spec.launches()):     # (f32 slabs of the third program fit the LDS interpreter: one launch anyway)
             assert any("k_product_ell_chain<" in l for l in spec.launches()), (k, spec.launches())
             assert len(spec2.launches()) == len(spec.launches()) + 1, (k, spec.launches(), spec2.launches())
-        if dtype == ga.F64:
-            want, wmask = oracle_eval_batch(build, n, rows, batch)
-            assert mask == wmask and np.array_equal(got, want), k
+        rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+        want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
+        assert mask == wmask and np.array_equal(got.astype(np.float64), want), k

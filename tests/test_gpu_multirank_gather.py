@@ -102,3 +102,31 @@ def test_a_gather_whose_sends_and_receives_do_not_pair_up_fails_loudly(tmp_path)
     rc = spawn_ranks([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "comm.id"), so, "0", "1", "0",
                       "10", "10"], 2, env_extra={"GAAST_TEST_ROOT_MISCOUNT": "1", "GAAST_RCCL_STUB_TIMEOUT_S": "20"}, timeout=300)
     assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root,failing", [(2, 0, 1), (3, 1, 2)])
+def test_one_rank_failing_its_evaluation_is_reported_by_every_rank(tmp_path, world, root, failing):
+    """A failure of gaast_hip_eval_gather is COLLECTIVE (include/gaast_hip.h): a non-root rank's evaluation fails
+    (GAAST_FLAG_DEBUG_FAIL_EVAL on that rank only); it still posts its transfers, nobody hangs, and the root -- which
+    now holds stale rows of that rank -- returns non-zero like every other rank instead of GAAST_OK."""
+    from gaast_amd.launch import free_port, rank_env
+    so = build_rccl_stub(tmp_path)
+    exe = build_c_host("gather_host", tmp_path)
+    counts = [9, 5, 7][:world]
+    rng = np.random.default_rng(11)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(rows_of(5, [0, 2, 4], sum(counts), rng).tobytes())
+        f.write(rows_of(5, [1], sum(counts), rng).tobytes())
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = rank_env(rank, world, port)
+        env.update({"GAAST_TEST_FAIL_EVAL_RANK": str(failing), "GAAST_RCCL_STUB_TIMEOUT_S": "60"})
+        procs.append(subprocess.Popen([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "comm.id"), so,
+                                       str(root), "3", "0"] + [str(c) for c in counts], env=env, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    codes = [p.returncode for p in procs]
+    # 42 = "gaast_hip_eval_gather returned the status the header promises": GAAST_ERR_HIP on the failing rank, GAAST_ERR_RCCL elsewhere
+    assert codes == [42] * world, (codes, [o[1][-500:] for o in outs])
+    assert "injected evaluation failure" in outs[failing][1] and "another rank failed" in outs[root][1]

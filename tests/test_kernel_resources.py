@@ -100,3 +100,18 @@ def test_library_revision_matches_the_sources_it_was_built_from():
     if os.environ.get("GAAST_HIP_LIB"):
         pytest.skip("an A/B build is selected")
     assert version.endswith(h.hexdigest()[:12]), (version, h.hexdigest()[:12])
+
+
+def test_a_change_of_the_build_switches_rebuilds_every_object_that_sees_them():
+    """KFLAGS reaches plan.cpp too (GAAST_JIT_NT, GAAST_INTERP_BUDGET_KB): with the revision hashing KFLAGS, a change of switches
+    in an existing object directory must recompile plan.o and runtime.o, or the library reports the new revision over old code
+    (make -n: nothing is built)."""
+    import os
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaast_amd", "csrc")
+    if not os.path.isdir(os.path.join(csrc, "_obj")):
+        pytest.skip("no object directory (the library was not built in this tree)")
+    plain = subprocess.run(["make", "-n", "-C", csrc], capture_output=True, text=True, check=True).stdout
+    assert "plan.cpp" not in plain and "runtime.hip" not in plain, "the tree is not up to date: run build() first"
+    dry = subprocess.run(["make", "-n", "-C", csrc, "KFLAGS=-DGAAST_INTERP_BUDGET_KB=96"], capture_output=True, text=True, check=True).stdout
+    assert "device/plan.cpp" in dry and "device/runtime.hip" in dry and "host/expr.cpp" in dry, dry

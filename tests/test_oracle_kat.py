@@ -39,6 +39,10 @@ def expr_eq(case, expr):
     # the reference runs its tests in debug builds (overflow checks on): must not panic there
     out_dbg = expr.specialize(_metric(case["metric"])).eval(mode=og.EVAL_DEBUG)
     assert out_dbg == out
+    # the oracle's F32 MODE (every operand and result rounded to binary32; the checker of the f32 exact kernels) is pinned by
+    # the same four known answers: their inputs, intermediates and results are exactly representable in binary32
+    out_f32 = expr.specialize(_metric(case["metric"])).eval(mode=og.EVAL_F32)
+    assert out_f32 == out
 
 
 # ---- src/eval.rs:134-163 -----------------------------------------------------------------
@@ -179,3 +183,34 @@ def test_hash_map_mv_eq(kat):
     assert grade_map_mv(d) == grade_map_mv(d)
     assert grade_map_mv(d) != grade_map_mv({1: [1, 2, 4]})
     assert grade_map_mv(d) != grade_map_mv({2: [1, 2, 3]})
+
+
+def test_f32_mode_rounds_every_operation_to_binary32():
+    """OG_EVAL_F32 is not `compute in f64, round at the end`: a sum whose f64 and f32 evaluations differ must come out as the
+    sequential binary32 evaluation (numpy float32 arithmetic, the same statements in the same order: eval.rs:82)."""
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, 8).astype(np.float32)
+    b = rng.uniform(-1, 1, 8).astype(np.float32)
+    full = [0, 1, 2, 3]
+    mk = lambda v: og.mv(grade_map_mv({0: [float(v[0])], 1: [float(x) for x in v[1:4]], 2: [float(x) for x in v[4:7]], 3: [float(v[7])]}))
+    spec = (mk(a) * mk(b)).specialize(3)
+    out32 = spec.eval(mode=og.EVAL_F32)
+    out64 = spec.eval()
+    # sequential binary32 evaluation of the same list
+    root = spec.nodes()[spec.root()]
+    res = {k: np.zeros(len(out64.grade_slice(k)), dtype=np.float32) for k in full}
+    sl = lambda v, k: {0: v[0:1], 1: v[1:4], 2: v[4:7], 3: v[7:8]}[k]
+    la = np.float32(0) + a   # the operand copies of eval.rs:27-31 (0.0 + x)
+    lb = np.float32(0) + b
+    for (lg, li, rg, ri, og_, oi, coeff) in spec.comp_muls(spec.root()):
+        prod = np.float32(sl(la, lg)[li] * sl(lb, rg)[ri])
+        prod = np.float32(prod * np.float32(coeff))
+        res[og_][oi] = np.float32(res[og_][oi] + prod)
+    differs = False
+    for k in full:
+        got = np.asarray(out32.grade_slice(k))
+        assert np.array_equal(got, res[k].astype(np.float64)), (k, got, res[k])
+        assert np.array_equal(got, got.astype(np.float32).astype(np.float64))   # every value is a binary32 value
+        differs |= not np.array_equal(got, np.asarray(out64.grade_slice(k)).astype(np.float32).astype(np.float64))
+    assert differs, "the case does not tell the f32 mode from a rounded f64 evaluation"
+    assert root.minimal == 0xF
