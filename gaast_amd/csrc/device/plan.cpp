@@ -489,7 +489,7 @@ struct Lowering {
         return true;
     }
 
-    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>, 5 = k_gp_mfma7<T>), in which algebra
+    // which dense kernel (0 = none, 1 = k_gp_dense, 3 = k_gp_mfma32 / k_gp_mfma32p, 4 = k_gp_mfma16x4<T>, 5 = k_gp_mfma7<T>, 6 = k_gp_mfma6<T>), in which algebra
     // (frame) and in which basis of it (perm)
     int dense_kind_for(const DenseFrame& f, uint64_t n_comp_muls, std::vector<int>& perm) const {
         const int n = f.n;
@@ -509,6 +509,9 @@ struct Lowering {
             return 4;
         // n = 7, both value types: one wave per item on the 16x16x4 instructions (lo = 3 bits: three non-null vectors)
         if (n == 7 && !(plan.flags & GAAST_FLAG_NO_MFMA) && dense_basis_permutation(f, 3, false, perm)) return 5;
+        // n = 6, both value types: four 16x16x4 instructions per item, ANY +-1 / 0 metric in the basis as it stands (signs and
+        // vanishing terms are slots of the operand images and bits of the accumulators: no lo vectors, no permutation)
+        if (n == 6 && !(plan.flags & GAAST_FLAG_NO_MFMA) && dense_basis_permutation(f, 0, false, perm)) return 6;
         if (dense_basis_permutation(f, 4, true, perm)) return 1;
         return 0;
     }
@@ -691,6 +694,7 @@ struct Lowering {
             s.use_mfma16 = dense_kind == 4;
             s.use_mfma16d = dense_kind == 4;
             s.use_mfma7 = dense_kind == 5;
+            s.use_mfma6 = dense_kind == 6;
             s.mfma16_quads = dense_kind == 4 && plan.dtype == GAAST_F32;   // k_gp_mfma16x4<float>: B words in 16-byte quads
             s.mfma32_pairs = dense_kind == 3 && n2 <= 13;   // k_gp_mfma32p: +A, -A, +B, -B images (n = 14 does not fit)
             // blade R of the frame's basis <-> blade R' of its permuted basis, f_R = sign(R) f'_R' (the parity of the
@@ -811,7 +815,8 @@ struct Lowering {
                         if (s.mfma32_pairs && right) neg ^= uint32_t(__builtin_popcount(blade >> 5) & __builtin_popcount(blade & 31u) & 1);
                         if (s.use_mfma7 && right) neg ^= uint32_t(__builtin_popcount((blade >> 3) & 7u) & __builtin_popcount(blade & 7u) & 1);
                         const uint32_t sgn = neg ? 0x80000000u : 0u;
-                        const uint32_t pos = s.use_mfma7 ? (right ? mfma7_b_pos(blade) : mfma7_a_pos(blade))
+                        const uint32_t pos = s.use_mfma6 ? blade   // k_gp_mfma6 derives its image slots from the blade itself
+                                             : s.use_mfma7 ? (right ? mfma7_b_pos(blade) : mfma7_a_pos(blade))
                                              : s.mfma32_pairs ? (right ? mfma32p_b_pos(blade) : blade)
                                              : s.use_mfma ? (right ? mfma_b_pos(blade) : blade)
                                              : s.mfma16_quads ? (right ? mfma16q_b_pos(blade) : blade)
@@ -879,7 +884,7 @@ struct Lowering {
             for (uint32_t m = 0; m < (1u << n2); ++m) s.out_full = s.out_full && s.i32_a[m] >= 0;
             for (uint32_t w : s.u32_a) s.left_signs |= int(w >> 31);
             for (int32_t w : s.i32_a) s.out_signs |= int(w >= 0 && (uint32_t(w) & 0x40000000u));
-            const int lo_bits = s.use_mfma ? 5 : s.use_mfma7 ? 3 : 4;
+            const int lo_bits = s.use_mfma ? 5 : s.use_mfma7 ? 3 : s.use_mfma6 ? 0 : 4;
             for (int j = 0; j < n2; ++j) {
                 const double g = frame.metric[size_t(perm[size_t(j)])];   // only its sign matters here: the magnitude is in the scales
                 if (j < lo_bits) {
@@ -1576,7 +1581,7 @@ static void chain_sparse_into_dense(Plan& plan) {
     auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
     for (size_t j = 0; j < plan.steps.size(); ++j) {
         Step& dn = plan.steps[j];
-        if (dn.kind != Step::PRODUCT_DENSE || dn.use_spinor || dn.chained || dn.a.kind != BufKind::NODE) continue;
+        if (dn.kind != Step::PRODUCT_DENSE || dn.use_spinor || dn.use_mfma6 || dn.chained || dn.a.kind != BufKind::NODE) continue;   // (k_gp_mfma6 has no chained staging: programs that small are fused whole)
         const BufRef buf = dn.a;
         // exactly one writer (a list product that starts the buffer: beta = 0), no other reader, nothing else touches it
         int writer = -1;
@@ -1685,6 +1690,249 @@ static void chain_sparse_into_dense(Plan& plan) {
     plan.steps = std::move(kept);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The list chain specialised per program (round 4; the generic k_product_ell_chain is the fallback when hiprtc is not
+// available).  What the generic kernel paid for: run-time widths and lengths, a row-per-lane first list whose 64 lanes gather
+// 64 different offsets of ONE item (bank conflicts: 39 % of the LDS cycles), nine vector instructions per term.  Here:
+//   * lane = (row, item) in BOTH lists, the IPB items of the workgroup fastest: the lanes of one LDS access group read the
+//     SAME offset of different items, item stride odd (in elements) -> no bank conflict at IPB = 32;
+//   * an entry is one word of byte offsets from the ITEM's base: list 1 [15:0] left | [31:16] right, the sign folded into
+//     the choice between the smaller operand's image and its NEGATED image (l * (-r) = -(l * r) exactly: eval.rs:82 with
+//     coeff = -1); list 2 [15:0] mid | [30:16] other | [31] sign, applied as fma(l * r, +-1.0, acc): the product is rounded
+//     first, +-1 is exact, the sum is rounded once -- the reference's three roundings;
+//   * entries are read from global memory (the tables are shared by every workgroup and stay in L2 / L1), a quad of entries
+//     per 16-byte load, the next quads in flight while the current ones are used; no run-time width, no padding terms
+//     (acc + (+0.0) would turn a -0.0 accumulator of a beta = 1 list into +0.0);
+//   * reference order and roundings: bit-identical to the two-launch plan and to the oracle.
+// ---------------------------------------------------------------------------------------------------------------------
+static void make_chain_jit(const Plan& plan, Step& c, const Step& w, int64_t l1, int64_t r1, int64_t mid, int64_t r2, int alias, int side,
+                           bool covered) {
+    if (plan.flags & (GAAST_FLAG_NO_JIT | GAAST_FLAG_DEBUG_JIT_FAILS)) return;
+    const int64_t esz = plan.dtype == GAAST_F32 ? 4 : 8;
+    const int64_t neg_len = std::min(l1, r1);
+    const bool neg_is_left = l1 < r1;
+    // layout of an item in LDS (elements): list 2's own operand first (its offsets have 15 bits), then the rest
+    int64_t off_l1 = 0, off_r1 = 0, off_neg, off_mid, off_r2 = -1, cur = 0;
+    auto place = [&](int64_t len) { const int64_t o = cur; cur += len; return o; };
+    if (alias == 0) off_r2 = place(r2);
+    if (alias == 2) { off_r1 = place(r1); off_l1 = place(l1); }
+    else { off_l1 = place(l1); off_r1 = place(r1); }
+    off_neg = place(neg_len);
+    off_mid = place(mid);
+    int64_t stride = cur | 1;   // odd: lanes reading one offset of consecutive items touch consecutive banks (bank pairs in f64)
+    const int64_t off_other = alias == 0 ? off_r2 : alias == 1 ? off_l1 : off_r1;
+    const int64_t other_len = alias == 0 ? r2 : alias == 1 ? l1 : r1;
+    if ((off_other + other_len) * esz > 32768 || stride * esz > 65535) return;
+    const int64_t rows1 = int64_t(w.u32_b.size()), rows2 = int64_t(c.u32_b.size());
+    const int64_t w1 = w.ell_width, w2 = c.ell_width;
+    if (rows1 <= 0 || rows2 <= 0 || w1 <= 0 || w2 <= 0 || w1 > 32) return;   // (list 1's operands of a row are all in flight at once)
+    // items per workgroup: a power of two up to 32 (the lanes of an LDS access group), as many as the LDS holds
+    int64_t ipb = 32;
+    const int64_t lds_cap = int64_t(kLdsBytes) - 2048;
+    while (ipb > 1 && ipb * stride * esz > lds_cap) ipb >>= 1;
+    if (ipb < 2) return;
+    int64_t threads = (rows2 * ipb + 63) / 64 * 64;   // list 2 (few long rows) in one pass
+    threads = std::max<int64_t>(256, std::min<int64_t>(1024, threads));
+    const int64_t w1p = (w1 + 3) & ~int64_t(3), w2p = (w2 + 3) & ~int64_t(3);
+    // tables
+    c.cj_ent1.assign(size_t(rows1 * w1p), 0u);
+    c.cj_pos1.resize(size_t(rows1));
+    for (int64_t row = 0; row < rows1; ++row) {
+        c.cj_pos1[size_t(row)] = uint32_t((off_mid + int64_t(w.u32_b[size_t(row)])) * esz);
+        for (int64_t t = 0; t < w1; ++t) {
+            const uint32_t e = w.u32_c[size_t(t * rows1 + row)];
+            const bool neg = (e & 0x80000000u) != 0;
+            const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;   // bytes, from the operand rows
+            const int64_t la = ((neg && neg_is_left) ? off_neg : off_l1) * esz + lo;
+            const int64_t ra = ((neg && !neg_is_left) ? off_neg : off_r1) * esz + ro;
+            c.cj_ent1[size_t(row * w1p + t)] = uint32_t(la) | (uint32_t(ra) << 16);
+        }
+    }
+    c.cj_ent2.assign(size_t(rows2 * w2p), 0u);
+    c.cj_out2 = c.u32_b;
+    for (int64_t row = 0; row < rows2; ++row)
+        for (int64_t t = 0; t < w2; ++t) {
+            const uint32_t e = c.u32_c[size_t(t * rows2 + row)];
+            const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;
+            const int64_t ma = off_mid * esz + (side == 1 ? lo : ro), oa = off_other * esz + (side == 1 ? ro : lo);
+            c.cj_ent2[size_t(row * w2p + t)] = uint32_t(ma) | (uint32_t(oa) << 16) | (e & 0x80000000u);
+        }
+    // the tables ride in LDS when they fit beside the items (list 2's first: its words are read once per term by few lanes);
+    // a table that does not fit is read from global memory (L1 / L2), a quad of entries per 16-byte load
+    const int64_t items_bytes = (ipb * stride * esz + 15) / 16 * 16;
+    const int64_t ent2_bytes = rows2 * w2p * 4, ent1_bytes = rows1 * w1p * 4;
+    const bool ent2_lds = items_bytes + ent2_bytes <= int64_t(kLdsBytes);
+    const bool ent1_lds = items_bytes + (ent2_lds ? ent2_bytes : 0) + ent1_bytes <= int64_t(kLdsBytes);
+    // source
+    std::string src;
+    auto def = [&](const char* name, int64_t v) { src += std::string("#define ") + name + " " + std::to_string(v) + "\n"; };
+    src += plan.dtype == GAAST_F32 ? "typedef float T;\n#define F64 0\n" : "typedef double T;\n#define F64 1\n";
+    def("ESZ", esz); def("NT", threads); def("IPB", ipb); def("NSUB", threads / ipb); def("STRIDE_B", stride * esz);
+    def("L1", l1); def("R1", r1); def("R2", alias ? 0 : r2); def("MID", mid); def("NEGLEN", neg_len); def("NEG_IS_LEFT", neg_is_left ? 1 : 0);
+    def("OFF_L1", off_l1 * esz); def("OFF_R1", off_r1 * esz); def("OFF_NEG", off_neg * esz); def("OFF_MID", off_mid * esz);
+    def("OFF_R2", (alias ? 0 : off_r2) * esz); def("HAS_R2", alias ? 0 : 1);
+    def("ROWS1", rows1); def("W1", w1); def("W1P", w1p); def("ROWS2", rows2); def("W2", w2); def("W2P", w2p);
+    def("CANON_L1", w.canon_a); def("CANON_R1", w.canon_b); def("CANON_R2", side == 1 ? c.canon_b : c.canon_a);
+    def("CANON_MID", side == 1 ? c.canon_a : c.canon_b); def("COVERED", covered ? 1 : 0); def("BETA", c.beta);
+    def("ITEMS_BYTES", items_bytes); def("ENT2_LDS", ent2_lds ? 1 : 0); def("ENT1_LDS", ent1_lds ? 1 : 0);
+    def("ENT2_AT", items_bytes); def("ENT1_AT", items_bytes + (ent2_lds ? ent2_bytes : 0));
+    def("SMEM_BYTES", items_bytes + (ent2_lds ? ent2_bytes : 0) + (ent1_lds ? ent1_bytes : 0));
+    src += R"JIT(
+typedef unsigned int u32;
+typedef unsigned long long u64;
+struct __attribute__((aligned(16))) q4 { u32 x, y, z, w; };
+#if F64
+#define ONE_HI 0x3ff00000u
+__device__ __forceinline__ T sgn_of(u32 e, u32 one_hi) {
+    u32 hi;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(e), "s"(0x80000000u), "v"(one_hi));   // +-1.0: the high word; the low word is 0
+    return __builtin_bit_cast(double, ((u64)hi) << 32);
+}
+#define FMA(a, b, c) __builtin_fma(a, b, c)
+#else
+#define ONE_HI 0x3f800000u
+__device__ __forceinline__ T sgn_of(u32 e, u32 one_hi) {
+    u32 hi;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(e), "s"(0x80000000u), "v"(one_hi));
+    return __builtin_bit_cast(float, hi);
+}
+#define FMA(a, b, c) __builtin_fmaf(a, b, c)
+#endif
+#define LDS(addr) (*(const T*)(smem + (addr)))
+__device__ __forceinline__ u32 word_of(const q4& e4, int t) { return (t & 3) == 0 ? e4.x : (t & 3) == 1 ? e4.y : (t & 3) == 2 ? e4.z : e4.w; }
+
+// operand rows of the group's items, element e = item * LEN + c of the flattened range; rows beyond the batch are zero
+template <int LEN, int CANON, int OFF, int NEGOFF>
+__device__ __forceinline__ void stage(unsigned char* smem, const T* __restrict__ src, long long stride, long long item0, int nitems, int tid) {
+    constexpr int TOTAL = IPB * LEN;
+#pragma unroll 4
+    for (int e = tid; e < TOTAL; e += NT) {
+        const int i2 = e / LEN, c = e - i2 * LEN;
+        T v = i2 < nitems ? src[(item0 + i2) * stride + c] : T(0);
+        if (CANON) v = T(0) + v;                                  // init_null_mv + add_grades_from: 0.0 + x (eval.rs:27-31)
+        *(T*)(smem + i2 * STRIDE_B + OFF + c * ESZ) = v;
+        if (NEGOFF >= 0) *(T*)(smem + i2 * STRIDE_B + NEGOFF + c * ESZ) = -v;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict__ l1, long long s_l1, const T* __restrict__ r1, long long s_r1,
+                                                              const T* __restrict__ r2, long long s_r2, T* __restrict__ out, long long s_out,
+                                                              const u32* __restrict__ ent1, const u32* __restrict__ pos1,
+                                                              const u32* __restrict__ ent2, const u32* __restrict__ out2, long long batch) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int it = tid & (IPB - 1), sub = tid / IPB;
+    const u32 base = u32(it) * STRIDE_B;
+    u32 one_hi = ONE_HI;
+    asm volatile("" : "+v"(one_hi));   // a vector register (the and-or takes one scalar operand)
+    // the tables, once per (persistent) workgroup
+#if ENT2_LDS
+    for (int e = tid; e < ROWS2 * W2P / 4; e += NT) ((q4*)(smem + ENT2_AT))[e] = ((const q4*)ent2)[e];
+    const q4* const tab2 = (const q4*)(smem + ENT2_AT);
+#else
+    const q4* const tab2 = (const q4*)ent2;
+#endif
+#if ENT1_LDS
+    for (int e = tid; e < ROWS1 * W1P / 4; e += NT) ((q4*)(smem + ENT1_AT))[e] = ((const q4*)ent1)[e];
+    const q4* const tab1 = (const q4*)(smem + ENT1_AT);
+#else
+    const q4* const tab1 = (const q4*)ent1;
+#endif
+    const long long groups = (batch + IPB - 1) / IPB;
+    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {   // persistent workgroups
+        const long long item0 = g * IPB;
+        const int nitems = int(batch - item0 < IPB ? batch - item0 : IPB);
+        stage<L1, CANON_L1, OFF_L1, (NEG_IS_LEFT ? OFF_NEG : -1)>(smem, l1, s_l1, item0, nitems, tid);
+        stage<R1, CANON_R1, OFF_R1, (NEG_IS_LEFT ? -1 : OFF_NEG)>(smem, r1, s_r1, item0, nitems, tid);
+#if HAS_R2
+        stage<R2, CANON_R2, OFF_R2, -1>(smem, r2, s_r2, item0, nitems, tid);
+#endif
+#if !COVERED
+        for (int e = tid; e < IPB * MID; e += NT) *(T*)(smem + (e / MID) * STRIDE_B + OFF_MID + (e % MID) * ESZ) = T(0);
+#endif
+        __syncthreads();
+        // ---- list 1 -> mid (eval.rs:77-83 into the fresh cache buffer of eval.rs:21-33): the operands of row k + 1 are in
+        // flight while row k's chain is evaluated (two register sets, the loop unrolled by two: no copies) ----
+        {
+            T la[W1], ra[W1], lb[W1], rb[W1];
+            auto load1 = [&](T (&lv)[W1], T (&rv)[W1], int row) {
+#pragma unroll
+                for (int t = 0; t < W1; ++t) {
+                    const u32 e = word_of(tab1[row * (W1P / 4) + t / 4], t);
+                    lv[t] = LDS(base + (e & 0xffffu));
+                    rv[t] = LDS(base + (e >> 16));
+                }
+            };
+            auto sum1 = [&](const T (&lv)[W1], const T (&rv)[W1], int row) {
+                T acc = T(0);
+#pragma unroll
+                for (int t = 0; t < W1; ++t) acc = acc + lv[t] * rv[t];      // (l * r) * (+-1) then +=: the sign rides in the image
+                *(T*)(smem + base + pos1[row]) = CANON_MID ? T(0) + acc : acc;
+            };
+            constexpr int LAST1 = ROWS1 - 1;
+            int row = sub;
+            if (row < ROWS1) load1(la, ra, row);
+#pragma nounroll
+            for (; row < ROWS1; row += 2 * NSUB) {
+                const int r2_ = row + NSUB, r3_ = row + 2 * NSUB;
+                load1(lb, rb, r2_ < ROWS1 ? r2_ : LAST1);
+                sum1(la, ra, row);
+                load1(la, ra, r3_ < ROWS1 ? r3_ : LAST1);
+                if (r2_ < ROWS1) sum1(lb, rb, r2_);
+            }
+        }
+        __syncthreads();
+        // ---- list 2: (mid, other operand) -> out; sixteen terms' operands in flight while the previous sixteen are summed ----
+#pragma nounroll
+        for (int row = sub; row < ROWS2; row += NSUB) {
+            const u32 oo = out2[row];
+            T acc = (BETA && it < nitems) ? out[(item0 + it) * s_out + oo] : T(0);
+            const q4* ep = tab2 + row * (W2P / 4);
+            constexpr int NB = W2 / 16;                  // batches of sixteen terms
+            T ma[16], oa[16], sa[16], mb[16], ob[16], sb[16];
+            auto load2 = [&](T (&mv)[16], T (&ov)[16], T (&sg)[16], int b) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const u32 e = word_of(ep[4 * b + t / 4], t);
+                    mv[t] = LDS(base + (e & 0xffffu));
+                    ov[t] = LDS(base + ((e >> 16) & 0x7fffu));
+                    sg[t] = sgn_of(e, one_hi);
+                }
+            };
+            auto sum2 = [&](const T (&mv)[16], const T (&ov)[16], const T (&sg)[16]) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = FMA(mv[t] * ov[t], sg[t], acc);   // eval.rs:82
+            };
+            if (NB > 0) load2(ma, oa, sa, 0);
+            int b = 0;
+#pragma nounroll
+            for (; b + 2 <= NB; b += 2) {
+                load2(mb, ob, sb, b + 1);
+                sum2(ma, oa, sa);
+                load2(ma, oa, sa, b + 2 < NB ? b + 2 : NB - 1);
+                sum2(mb, ob, sb);
+            }
+            if (NB & 1) sum2(ma, oa, sa);
+#pragma unroll
+            for (int t = NB * 16; t < W2; ++t) {         // the remainder (compile-time count, no padding terms)
+                const u32 e = word_of(ep[t / 4], t);
+                acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), sgn_of(e, one_hi), acc);
+            }
+            if (it < nitems) out[(item0 + it) * s_out + oo] = acc;
+        }
+        __syncthreads();   // the rows are rewritten by the next group
+    }
+}
+)JIT";
+    c.chain_jit = 1;
+    c.chain_jit_source = std::move(src);
+    const int64_t lay[7] = {off_l1, off_r1, off_neg, off_mid, alias ? -1 : off_r2, stride, neg_is_left ? 1 : 0};
+    for (int i = 0; i < 7; ++i) c.cj_layout[i] = int(lay[i]);
+    c.cj_ipb = int(ipb);
+    c.cj_threads = int(threads);
+    c.cj_lds = size_t(items_bytes + (ent2_lds ? ent2_bytes : 0) + (ent1_lds ? ent1_bytes : 0));
+}
+
 // A list product whose result is read ONLY by another list product (as either operand): both run in ONE k_product_ell_chain
 // launch with the mid row in LDS -- the rotor sandwich applied to a vector, (R X ~R).g(1), where it no longer fits a fused
 // small-program kernel (n >= 9) and its second product (n rows of 2^(n-1) terms) is far too sparse for the dense kernels.  Same
@@ -1774,6 +2022,7 @@ static void chain_list_into_list(Plan& plan) {
             c.pre_width = w.ell_width;
             c.name += " <- " + w.name + " in LDS";
             c.n_entries += w.n_entries;
+            make_chain_jit(plan, c, w, l1, r1, mid, r2, alias, side, covered);
             (side == 1 ? c.a : c.b) = BufRef{BufKind::NODE, -1};
             plan.node_dead[size_t(buf.idx)] = 1;
             w.kind = Step::ZERO;   // marks the first list for removal below

@@ -102,9 +102,24 @@ struct Step {
     int chain_alias = 0;                 // this list's other operand: 0 = a row of its own, 1 = the first list's left row, 2 = its right row
     int chain_mid_len = 0, chain_canon_mid = 0, chain_covered = 0;
     int chain_ipb = 0, chain_item_stride = 0, chain_ent2_lds = 0;   // (bytes of this list's words kept in LDS, or 0)
+    // ... specialised per program through hiprtc (plan.cpp: chain_jit_source; round 4): lane = (row, item) in BOTH lists with the items
+    // of a workgroup fastest, so that the 32 lanes of an LDS access read one row's operand of 32 different items (odd item stride:
+    // no bank conflict); entries carry byte offsets from the item's base (list 1: the sign is folded into a negated image of the
+    // smaller operand); compile-time widths, lengths and strides.  The generic k_product_ell_chain stays as the fallback.
+    int chain_jit = 0;                   // 1: chain_jit_source is to be compiled (runtime.hip), 2: compiled and in charge
+    std::string chain_jit_source;
+    std::vector<uint32_t> cj_ent1, cj_pos1, cj_ent2, cj_out2;
+    void* d_cj_ent1 = nullptr;
+    void* d_cj_pos1 = nullptr;
+    void* d_cj_ent2 = nullptr;
+    void* d_cj_out2 = nullptr;
+    int cj_ipb = 0, cj_threads = 0;
+    size_t cj_lds = 0;
+    int cj_layout[7] = {0, 0, 0, 0, 0, 0, 0};   // an item in LDS, elements: offsets of l1, r1, the negated image, mid, r2 (-1: aliased); item stride; negated image is of the left operand
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)
+    int use_mfma6 = 0;   // k_gp_mfma6<T> (n = 6: four 16x16x4 instructions per item, the two top vectors split over the tile's rows and columns)
     int use_mfma7 = 0;   // k_gp_mfma7<T> (n = 7: lo = 3 bits, the top vector split over the two sides of the 16 x 16 tile)
     int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout
     int mfma32_pairs = 0;  // k_gp_mfma32p (image-pair form, f32, n = 10 ... 13) instead of k_gp_mfma32

@@ -101,7 +101,7 @@ namespace {
 void release_plan_resources(Plan& plan) {
     for (Step& s : plan.steps) {
         for (void** p : {&s.d_a, &s.d_b, &s.d_c, &s.d_coeff, &s.d_i32, &s.d_coeff_b, &s.d_coeff_c, &s.d_pre_row_start, &s.d_pre_entries,
-                         &s.d_pre_coeff, &s.d_pre_row_map, &s.d_pre_row_scale}) {
+                         &s.d_pre_coeff, &s.d_pre_row_map, &s.d_pre_row_scale, &s.d_cj_ent1, &s.d_cj_pos1, &s.d_cj_ent2, &s.d_cj_out2}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -222,6 +222,16 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             return set_err(GAAST_ERR_UNIMPLEMENTED,
                            "product operands of " + std::to_string(per_item) + " bytes per item do not fit the " +
                                std::to_string(g_max_lds) + "-byte LDS of the list kernels (" + s.name + ")");
+        if (s.list_chain && s.chain_jit == 2) {
+            // the chain specialised through hiprtc (plan.cpp: make_chain_jit): static LDS, persistent workgroups
+            s.threads = s.cj_threads;
+            s.lds = s.cj_lds;
+            s.hip_kernel = "gaast_chain<" + tn + ">[" + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads]";
+            int per_cu = 0;
+            HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, static_cast<hipFunction_t>(s.jit_function), s.threads, 0));
+            s.blocks_per_cu = per_cu < 1 ? 1 : per_cu;
+            return GAAST_OK;
+        }
         if (s.list_chain) {
             // two lists in one launch, the mid row in LDS (plan.cpp: chain_list_into_list): IPB items per workgroup
             s.lds = size_t(s.chain_ent2_lds) + size_t(s.chain_item_stride) * size_t(s.chain_ipb) * sizeof(T);
@@ -352,6 +362,17 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
                 if (int st = allow_lds(s.kern[v], s.lds)) return st;
             return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);   // persistent workgroups
         }
+        if (s.use_mfma6) {
+            // k_gp_mfma6<T>: one wave per item, persistent single-wave workgroups, 2 KiB (f32) / 4 KiB (f64) of operand images
+            s.threads = 64;
+            s.items_per_block = 1;
+            s.lds = is_f64 ? 4096 : 2048;
+            using KernD = void (*)(DenseArgs<T>);
+            const KernD k6 = s.scaled ? &k_gp_mfma6<T, true> : &k_gp_mfma6<T, false>;
+            s.kern[0] = reinterpret_cast<const void*>(k6);
+            s.hip_kernel = "k_gp_mfma6<" + tn + (s.scaled ? ",true>" : ",false>");
+            return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
+        }
         if (s.use_mfma7) {
             // k_gp_mfma7<T>: one wave per item, single-wave workgroups
             s.threads = 64;
@@ -446,6 +467,21 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         break;
     }
     case Step::PRODUCT_CSR: {
+        if (s.list_chain && s.chain_jit == 2) {
+            const bool mid_left = s.list_chain == 1;
+            const Bound& other = s.chain_alias ? pre_a : (mid_left ? b : a);
+            const void *l1 = pre_a.ptr, *r1 = pre_b.ptr, *r2 = other.ptr;
+            long long s_l1 = pre_a.stride, s_r1 = pre_b.stride, s_r2 = other.stride, s_out = res.stride, nb = batch;
+            void* optr = res.ptr;
+            const void *e1 = s.d_cj_ent1, *p1 = s.d_cj_pos1, *e2 = s.d_cj_ent2, *o2 = s.d_cj_out2;
+            void* args[] = {&l1, &s_l1, &r1, &s_r1, &r2, &s_r2, &optr, &s_out, &e1, &p1, &e2, &o2, &nb};
+            int64_t blocks = (batch + s.cj_ipb - 1) / s.cj_ipb;
+            blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * s.blocks_per_cu);
+            // (the argument block is copied into the dispatch packet at call time, like run_jit's)
+            HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), unsigned(blocks), 1, 1, unsigned(s.threads), 1, 1, 0, g_stream,
+                                          args, nullptr));
+            break;
+        }
         if (s.list_chain) {
             EllChainArgs<T> q;
             const bool mid_left = s.list_chain == 1;
@@ -651,9 +687,9 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
 }
 
 // hiprtc specialisation of a fused plan; on any failure the LDS interpreter kernel stays in charge
-bool jit_compile(Step& s, std::string* log) {
+bool jit_compile(Step& s, const std::string& source, const char* entry, std::string* log) {
     hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, s.jit_source.c_str(), "gaast_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "gaast_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
     const hiprtcResult res = hiprtcCompileProgram(prog, 3, opts);
     if (res != HIPRTC_SUCCESS) {
@@ -681,7 +717,7 @@ bool jit_compile(Step& s, std::string* log) {
     // HIP's header does not say that hipModuleLoadData copies the image: it stays alive, in the step, for as long as the
     // module does (release_plan_resources frees it after hipModuleUnload).  std::move keeps code.data() where it is.
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
-    if (hipModuleGetFunction(&fn, mod, "gaast_jit") != hipSuccess) {
+    if (hipModuleGetFunction(&fn, mod, entry) != hipSuccess) {
         (void)hipModuleUnload(mod);
         return false;
     }
@@ -860,7 +896,7 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             if (s.kind != Step::FUSED || s.jit_source.empty()) continue;
             if (desc->flags & GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE) prog->plan.jit_source_kept += s.jit_source;
             std::string log;
-            const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, &log);
+            const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, s.jit_source, "gaast_jit", &log);
             if (ok)
                 s.name = "ast_jit" + s.name.substr(s.name.find('['));
             else if (!log.empty())
@@ -879,6 +915,16 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             return set_err(GAAST_ERR_INVALID_PROGRAM, ex.what());
         }
         if (!prog->plan.unsupported.empty()) return set_err(GAAST_ERR_UNIMPLEMENTED, prog->plan.unsupported);
+    }
+    // list chains specialised per program; on any failure the generic k_product_ell_chain stays in charge
+    for (Step& s : prog->plan.steps) {
+        if (s.chain_jit != 1) continue;
+        if (desc->flags & GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE) prog->plan.jit_source_kept += s.chain_jit_source;
+        std::string log;
+        const bool ok = jit_compile(s, s.chain_jit_source, "gaast_chain", &log);
+        if (!ok && !log.empty()) g_err = "hiprtc: " + log;
+        s.chain_jit = ok ? 2 : 0;
+        std::string().swap(s.chain_jit_source);
     }
     Plan& plan = prog->plan;
     auto layout_of = [&](BufRef r) -> Layout {
@@ -933,8 +979,17 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
         if (s.list_chain) {
             if (s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
             if (s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
-            if (int st = upload_vec(s.pre_entries, &s.d_pre_entries)) return st;
-            if (int st = upload_vec(s.pre_row_map, &s.d_pre_row_map)) return st;
+            if (s.chain_jit == 2) {
+                if (int st = upload_vec(s.cj_ent1, &s.d_cj_ent1)) return st;
+                if (int st = upload_vec(s.cj_pos1, &s.d_cj_pos1)) return st;
+                if (int st = upload_vec(s.cj_ent2, &s.d_cj_ent2)) return st;
+                if (int st = upload_vec(s.cj_out2, &s.d_cj_out2)) return st;
+            } else {
+                if (int st = upload_vec(s.pre_entries, &s.d_pre_entries)) return st;
+                if (int st = upload_vec(s.pre_row_map, &s.d_pre_row_map)) return st;
+            }
+            std::vector<uint32_t>().swap(s.cj_ent1);
+            std::vector<uint32_t>().swap(s.cj_ent2);
         }
         if (s.a.idx >= 0 && s.a.kind == BufKind::INPUT) plan.slot_used[size_t(s.a.idx)] = 1;
         if (s.b.idx >= 0 && s.b.kind == BufKind::INPUT) plan.slot_used[size_t(s.b.idx)] = 1;

@@ -4,6 +4,7 @@
 // undefined shift in the bitmask arithmetic aborts the run.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "gaast_expr.h"
@@ -226,7 +227,111 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     std::printf("ok  %s (%s)\n", what, st->name.c_str());
 }
 
-int main() {
+// The list chain specialised per program (plan.cpp: make_chain_jit): its tables are a TRANSFORMATION of the generic chain's
+// (byte offsets from the item's base in a new LDS layout, list 1's signs folded into a negated image).  Both table sets are
+// executed here, in plain C++ doubles in the kernels' order, on the same random rows: every result bit must agree.  With a
+// directory argument the generated kernel source is written there (tests/test_chain_jit.py compiles it for gfx950).
+static void chain_tables_agree(int n, const double* metric, int dtype, const char* dump_dir) {
+    gaast_expr_t r = gaast_expr_input(0, 0x5555555555555555ull & full_mask(n), n), x = gaast_expr_input(1, 0x2, n);
+    gaast_expr_t e = gaast_expr_g(gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC), 1);
+    gaast_spec_t spec = gaast_expr_specialize(e, n, metric, 1 << 16);
+    CHECK(spec != nullptr);
+    if (!spec) return;
+    gaast_program_desc desc;
+    CHECK(gaast_spec_program_desc(spec, dtype, 0, &desc) == 0);
+    gaast::Plan plan;
+    gaast::build_plan(desc, plan);
+    CHECK(plan.steps.size() == 1 && plan.steps[0].list_chain && plan.steps[0].chain_jit == 1);
+    if (plan.steps.size() != 1 || plan.steps[0].chain_jit != 1) {
+        gaast_spec_free(spec);
+        return;
+    }
+    const gaast::Step& s = plan.steps[0];
+    if (dump_dir) {
+        char path[512];
+        std::snprintf(path, sizeof path, "%s/chain_n%d_%s.hip", dump_dir, n, dtype == GAAST_F32 ? "f32" : "f64");
+        if (FILE* f = std::fopen(path, "w")) {
+            std::fputs(s.chain_jit_source.c_str(), f);
+            std::fclose(f);
+        }
+    }
+    const int esz = dtype == GAAST_F32 ? 4 : 8;
+    const int l1 = s.pre_left_len, r1 = s.pre_right_len, mid = s.chain_mid_len;
+    const int rows1 = int(s.pre_row_map.size()), w1 = s.pre_width, rows2 = int(s.u32_b.size()), w2 = s.ell_width;
+    const int w1p = (w1 + 3) & ~3, w2p = (w2 + 3) & ~3;
+    CHECK(int(s.cj_ent1.size()) == rows1 * w1p && int(s.cj_ent2.size()) == rows2 * w2p && s.chain_alias == 1 && s.list_chain == 1);
+    std::vector<double> L(static_cast<size_t>(l1), 0.0), X(static_cast<size_t>(r1), 0.0);
+    unsigned long long seed = 88172645463325252ull + unsigned(n);
+    auto rnd = [&]() {
+        seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+        return double(int64_t(seed >> 11)) / double(1ull << 52) - 1.0;
+    };
+    for (double& v : L) v = rnd();
+    for (double& v : X) v = rnd();
+    // (a) the generic tables: [term][row] words, byte offsets from each operand row, sign in bit 31
+    std::vector<double> mid_a(size_t(mid), 0.0), out_a(size_t(rows2), 0.0);
+    for (int row = 0; row < rows1; ++row) {
+        double acc = 0.0;
+        for (int t = 0; t < w1; ++t) {
+            const uint32_t w = s.pre_entries[size_t(t) * rows1 + row];
+            const double p = L[(w & 0x7fffu) / esz] * X[((w >> 16) & 0x7fffu) / esz];
+            acc = acc + ((w & 0x80000000u) ? -p : p);
+        }
+        mid_a[s.pre_row_map[size_t(row)]] = acc;
+    }
+    for (int row = 0; row < rows2; ++row) {
+        double acc = 0.0;
+        for (int t = 0; t < w2; ++t) {
+            const uint32_t w = s.u32_c[size_t(t) * rows2 + row];
+            const double p = mid_a[(w & 0x7fffu) / esz] * L[((w >> 16) & 0x7fffu) / esz];
+            acc = acc + ((w & 0x80000000u) ? -p : p);
+        }
+        out_a[size_t(row)] = acc;
+    }
+    // (b) the specialised kernel's tables over its item image
+    const int* lay = s.cj_layout;
+    std::vector<double> img(size_t(lay[5]), 0.0);
+    for (int c = 0; c < l1; ++c) img[size_t(lay[0] + c)] = L[size_t(c)];
+    for (int c = 0; c < r1; ++c) img[size_t(lay[1] + c)] = X[size_t(c)];
+    for (int c = 0; c < (lay[6] ? l1 : r1); ++c) img[size_t(lay[2] + c)] = -(lay[6] ? L[size_t(c)] : X[size_t(c)]);
+    auto at = [&](uint32_t byte_off) -> double& {
+        CHECK(byte_off % esz == 0 && byte_off / esz < uint32_t(lay[5]));
+        return img[byte_off / esz];
+    };
+    for (int row = 0; row < rows1; ++row) {
+        double acc = 0.0;
+        for (int t = 0; t < w1; ++t) {
+            const uint32_t w = s.cj_ent1[size_t(row) * w1p + t];
+            acc = acc + at(w & 0xffffu) * at(w >> 16);
+        }
+        at(s.cj_pos1[size_t(row)]) = acc;
+    }
+    bool same = true;
+    for (int row = 0; row < rows2; ++row) {
+        double acc = 0.0;
+        for (int t = 0; t < w2; ++t) {
+            const uint32_t w = s.cj_ent2[size_t(row) * w2p + t];
+            const double p = at(w & 0xffffu) * at((w >> 16) & 0x7fffu);
+            acc = acc + ((w & 0x80000000u) ? -p : p);
+        }
+        same = same && std::memcmp(&acc, &out_a[size_t(row)], sizeof acc) == 0 && s.cj_out2[size_t(row)] == s.u32_b[size_t(row)];
+    }
+    if (!same) std::printf("chain tables n=%d: the specialised tables compute another result\n", n);
+    CHECK(same);
+    gaast_spec_free(spec);
+}
+
+int main(int argc, char** argv) {
+    const char* dump_dir = argc > 1 ? argv[1] : nullptr;
+    {
+        const double euclid16[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        const double mixed9[9] = {1, 1, 1, 1, 1, 1, -1, -1, -1};
+        chain_tables_agree(8, euclid16, GAAST_F64, dump_dir);
+        chain_tables_agree(9, mixed9, GAAST_F64, dump_dir);
+        chain_tables_agree(10, euclid16, GAAST_F64, dump_dir);
+        chain_tables_agree(9, mixed9, GAAST_F32, dump_dir);
+        chain_tables_agree(12, euclid16, GAAST_F64, dump_dir);
+    }
     const double euclid[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     const double cga[5] = {1, 1, 1, 1, -1};
     const double mixed12[12] = {1, 1, -1, 1, -1, -1, -1, -1, 1, 1, -1, 1};      // lambda on bit 4

@@ -524,8 +524,14 @@ def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
     want, wmask = oracle_eval_batch(build, alg, rows, batch)
     got, mask, spec = hip_eval_batch(build, alg, rows, batch)
     assert mask == wmask
-    assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and "k_product_ell_chain<double>" in spec.launches()[0], spec.launches()
+    # the chain specialised per program through hiprtc (round 4) ...
+    assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and "gaast_chain<double>" in spec.launches()[0], spec.launches()
     assert np.array_equal(got, want)
+    # ... and the generic kernel it falls back to without run-time compilation (n = 8 without hiprtc: the LDS interpreter)
+    gen, _, spec3 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_NO_JIT)
+    assert len(spec3.launches()) == 1 and np.array_equal(gen, want), spec3.launches()
+    if n > 8:
+        assert "k_product_ell_chain<double>" in spec3.launches()[0], spec3.launches()
     two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN)
     assert len(spec2.launches()) == (2 if n > 8 else 1) and np.array_equal(two, want), spec2.launches()    # (n = 8 without the chain: the interpreter)
 
@@ -550,7 +556,9 @@ def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtyp
         two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
         assert np.array_equal(got, two), (k, spec.launches(), spec2.launches())
         if not any("ast_fused" in l for l in spec.launches()):     # (f32 slabs of the third program fit the LDS interpreter: one launch anyway)
-            assert any("k_product_ell_chain<" in l for l in spec.launches()), (k, spec.launches())
+            assert any("gaast_chain<" in l for l in spec.launches()), (k, spec.launches())
+            gen, _, spec3 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT)    # the generic kernel
+            assert np.array_equal(gen, two) and any("k_product_ell_chain<" in l or "ast_fused" in l for l in spec3.launches()), (k, spec3.launches())
             assert len(spec2.launches()) == len(spec.launches()) + 1, (k, spec.launches(), spec2.launches())
         rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
         want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
