@@ -136,6 +136,27 @@ def workload_spec(name):
                     flags=ga.FLAG_EXACT_ORDER if m.group(3) else 0,
                     label=f"rotor sandwich {'(R X ~R).g(1)' if g1 else 'R X ~R'} in {'R^{6,3}' if n == 9 else 'R^%d' % n}, R even ({half} components), X grade 1, f64"
                           + (", reference summation order" if m.group(3) else ""))
+    # ---- whole-AST programs beyond a bare product or the sandwich (round 4; eval.rs has ten arms) ----
+    m = re.fullmatch(r"(vinv|proj|cfg1_)(\d+)", name)
+    if m:
+        from math import comb
+        kind, n = m.group(1), int(m.group(2))
+        full = list(range(n + 1))
+        even = [k for k in full if k % 2 == 0]
+        half = 1 << (n - 1)
+        if kind == "vinv":      # the versor inverse a.rev() * a.norm_sq().sinv() of an even multivector (expr.rs:363-371): Reverse, Product -> grade 0, ScalarUnaryOp, Product
+            return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[even], build=lambda a: a.vinv(), entries=2 * half,
+                        default_batch=max(1024, min(1 << 22, (1 << 30) // (half * 8))),
+                        label=f"versor inverse a.rev() * a.norm_sq().sinv() in R^{n}, a even ({half} components), f64")
+        if kind == "proj":      # the projection known-answer test of eval.rs:152-163 on batched inputs: (v & bv) & bv.vinv(), v a vector, bv a bivector
+            return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[[1], [2]], build=lambda v, bv: (v & bv) & bv.vinv(),
+                        entries=3 * n * (n - 1), default_batch=1 << 22,
+                        label=f"projection (v & bv) & bv.vinv() in R^{n} (eval.rs:152-163 at scale), f64")
+        # README.md:20-22 / BASELINE configs[0] at scale: d = (a + b * c).g(2), a, b, c full multivectors; of a only grade 2 is read
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[full, full, full], build=lambda a, b, c: (a + b * c).g(2),
+                    entries=comb(n, 2) << n, default_batch=max(1024, min(1 << 20, (1 << 29) // ((1 << n) * 8))),
+                    read_len=comb(n, 2) + 2 * (1 << n),
+                    label=f"d = (a + b * c).g(2) in R^{n}, full operands (README.md:20-22), f64")
     m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x|ee|eo|oe|oo)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order), gp12f32ee (even x even)
     if m:
         n, dt, var = int(m.group(1)), m.group(2), m.group(3)
@@ -304,7 +325,10 @@ def roofline_of(wl, workload, spec, batch, kernel_ms, in_len, out_len):
     peak_tf = PEAK_FP32_TFLOPS if dtype == ga.F32 else PEAK_FP64_TFLOPS
     ach_tf = flops_item * batch / (kernel_ms * 1e-3) * 1e-12
     ach_gb = bytes_item * batch / (kernel_ms * 1e-3) * 1e-9
-    if dense:
+    # the BINDING roof is the one that allows fewer items per second: dense products are matrix / vector FMA bound from
+    # n = 7 on; at n = 6 (768 B and 8,192 flop per item in f32) the HBM roof binds
+    hbm_bound_dense = PEAK_HBM_GBPS * 1e9 / bytes_item < peak_tf * 1e12 / flops_item
+    if dense and not hbm_bound_dense:
         roof = {"bound": "mfma", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
                 "traffic": None,
                 "note": ("dense product: fp32 vector FMA peak == fp32 MFMA peak (157.3 TFLOP/s); " if dtype == ga.F32 else
@@ -320,7 +344,7 @@ def roofline_of(wl, workload, spec, batch, kernel_ms, in_len, out_len):
             roof["power_capped_frac_ceiling"] = min(1.0, cap_tf / peak_tf)
     else:
         roof = {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBPS,
-                "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s"}
+                "traffic": None, "note": f"{len(launches)} launches per evaluation; {ach_tf:.2f} TFLOP/s = {ach_tf / peak_tf:.4f} of the {'FP32' if dtype == ga.F32 else 'FP64'} roof"}
     roof["kernel"] = [l for l in launches if "product" in l][-1] if any("product" in l for l in launches) else launches[-1]
     traffic, source, stale = _traffic_for(workload, batch, [roof["kernel"]])
     roof["traffic"] = traffic
@@ -659,6 +683,7 @@ def main():
         items_total = global_batch * args.steps
         value = items_total / wall
         in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)      # shared inputs are read once, not per item
+        in_len = wl.get("read_len", in_len)                                # (a + b * c).g(2): of `a` only the wanted grade is read
         launches = spec.launches()
         roof = roofline_of(wl, args.workload, spec, batch, kernel_ms, in_len, out_len)
         res = {

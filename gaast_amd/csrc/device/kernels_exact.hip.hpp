@@ -12,7 +12,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_axpy_map(T* __restrict__ res, int64_t res_stride,
                                                   const T* __restrict__ in, int64_t in_stride,
                                                   const uint32_t* __restrict__ map, int n_map,
-                                                  int64_t batch) {
+                                                  int64_t batch, int beta) {
     const int64_t total = batch * n_map;
     for (int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
          idx += int64_t(gridDim.x) * blockDim.x) {
@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void k_axpy_map(T* __restrict__ res, int64_t r
         const int j = int(idx - item * n_map);
         const uint32_t m = map[j];
         T* r = res + item * res_stride + (m & 0xffffu);
-        *r = *r + in[item * in_stride + (m >> 16)];  // graded.rs:74  `*r = *r + i`
+        // graded.rs:74  `*r = *r + i`; beta = 0: res is the fresh (all +0.0) buffer of init_null_mv and this arm writes every
+        // component of it -- the zero fill is folded in: 0.0 + i
+        *r = (beta ? *r : T(0)) + in[item * in_stride + (m >> 16)];
     }
 }
 

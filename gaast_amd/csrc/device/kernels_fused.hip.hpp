@@ -30,12 +30,13 @@ namespace gaast {
 //              coefficient like eval.rs:82 (general metrics; rare).
 //   LINE_MISC  count[20:15] (<= 30); words 2.. = element-wise micro-ops, [31:28] opcode:
 //              ADD dst[11:0] src[23:12]   slab[dst] = slab[dst] + slab[src]     (graded.rs:74)
+//              COPY dst[11:0] src[23:12]  slab[dst] = 0.0 + slab[src]           (graded.rs:195-201 then :74)
 //              NEG dst                    slab[dst] = -slab[dst]                 (graded.rs:63)
 //              ZERO dst count[23:12]      slab[dst..dst+count) = 0.0             (graded.rs:195-201)
 //              INV / SQRT dst             eval.rs:106-109
 // ------------------------------------------------------------------------------------------
 enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3 };
-enum : uint32_t { UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5, UOP_INV = 6, UOP_SQRT = 7 };
+enum : uint32_t { UOP_ADD = 3, UOP_NEG = 4, UOP_ZERO = 5, UOP_INV = 6, UOP_SQRT = 7, UOP_COPY = 8 };
 
 constexpr int FUSED_MAX_INPUTS = 8;
 constexpr int FUSED_ITEMS = 64;    // items per workgroup: lane <-> item
@@ -76,6 +77,8 @@ __device__ __forceinline__ void fused_misc(uint32_t w, T* __restrict__ my) {
     T* d = my + (w & 0xfffu);
     if (op == UOP_ADD) {
         *d = *d + my[(w >> 12) & 0xfffu];
+    } else if (op == UOP_COPY) {   // the zero fill of a fresh buffer folded into its first add_grades_from: 0.0 + x
+        *d = T(0) + my[(w >> 12) & 0xfffu];
     } else if (op == UOP_NEG) {
         *d = -*d;
     } else if (op == UOP_ZERO) {

@@ -28,25 +28,43 @@ namespace gaast {
 // slot a_hi of the four lanes (kq, row (u, a_lo ^ kq)) that multiply it, likewise B -- eight 4-byte (8-byte) stores per
 // lane and item -- so that a lane's operands of all four instructions are ONE 16-byte read per operand (f64: two).
 // Missing components (operands that hold only some grades) are slots nobody writes: they stay zero from the initial clear.
+// Which lane moves which component is the host's choice (plan.cpp: build_map deals full operands by LDS bank; the B stores go
+// out in the slot order i ^ b_lo): no bank conflict on the eight stores.
 // DEPTH items are in flight per wave (two loads each): 32 waves x DEPTH x 512 B per CU hide the HBM latency.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t group_reorder_parity(uint32_t a, uint32_t b) {   // #{(p, q): p in a, q in b, p > q} mod 2, 2-bit groups
     return (((b & 1u) ? __builtin_popcount(a >> 1) : 0) + ((b & 2u) ? __builtin_popcount(a >> 2) : 0)) & 1u;
 }
 
-template <typename T, bool SCALED>
-__global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
+// FAST: both operands hold every blade, every blade is produced and nothing is accumulated (the host checks): no lane is
+// ever masked around a memory instruction, so the item loop is straight-line code and the waits for the prefetched rows are
+// COUNTED (vmcnt(N): loads and stores share one in-order counter) -- with a conditional store in the loop the compiler waits
+// for everything, the loads just issued for the item DEPTH ahead included (first version: 4,400 cycles per item and wave).
+#ifndef GAAST_MFMA6_DEPTH
+#define GAAST_MFMA6_DEPTH 4   /* (build switch for A/B runs) items in flight per wave: 4 measured best (8: -3 %) */
+#endif
+#ifndef GAAST_MFMA6_SPLIT
+#define GAAST_MFMA6_SPLIT 0   /* (build switch for A/B runs) two accumulator chains of two instructions instead of one of four: measured -4 % */
+#endif
+#ifndef GAAST_MFMA6_WAVES
+#define GAAST_MFMA6_WAVES 1   /* (build switch for A/B runs) independent waves per workgroup */
+#endif
+template <typename T, bool SCALED, bool FAST>
+__global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T> p) {
     typedef Mfma16x4<T> MM;
     constexpr bool F32 = sizeof(T) == 4;
-    constexpr int ES = MM::SHIFT, DEPTH = 4;
+    constexpr int ES = MM::SHIFT, DEPTH = GAAST_MFMA6_DEPTH;
     // LDS (bytes): A image, then B image; f32: lane * 16 + slot * 4; f64: (slot >> 1) * 1024 + lane * 16 + (slot & 1) * 8 -- a
     // lane's 16-byte reads of one half are consecutive over the lanes (no bank conflict)
     constexpr uint32_t IMG = F32 ? 1024u : 2048u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    lds_u8* lds = (lds_u8*)smem_raw;
+    // every wave of the workgroup is on its own: its items, its images (no workgroup barrier anywhere)
+    constexpr int WAVES = GAAST_MFMA6_WAVES;
+    const int wave_id = int(threadIdx.x) >> 6;
+    lds_u8* lds = (lds_u8*)smem_raw + uint32_t(wave_id) * 2u * IMG;
     typedef __attribute__((address_space(3))) T lds_t;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < int(2 * IMG / 4); e += 64) reinterpret_cast<uint32_t*>(smem_raw)[e] = 0u;
+    const int tid = int(threadIdx.x) & 63;
+    for (int e = tid; e < int(2 * IMG / 4); e += 64) reinterpret_cast<uint32_t*>(smem_raw + size_t(wave_id) * 2 * IMG)[e] = 0u;
     auto slot_addr = [&](uint32_t lane, uint32_t slot) -> uint32_t {
         return F32 ? lane * 16u + slot * 4u : (slot >> 1) * 1024u + lane * 16u + (slot & 1u) * 8u;
     };
@@ -55,7 +73,7 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
     const uint32_t NEG_L = neg & 3u, NEG_H = (neg >> 2) & 3u, NEG_T = neg >> 4, Z_L = zero & 3u, Z_H = (zero >> 2) & 3u, Z_T = zero >> 4;
 
     // ---- this lane's components: entry `tid` of each operand map (row offset | blade << 16 | negate << 31) ----
-    const bool has_a = tid < p.left_count, has_b = tid < p.right_count;
+    const bool has_a = FAST || tid < p.left_count, has_b = FAST || tid < p.right_count;
     const uint32_t ma = has_a ? p.left_map[tid] : 0u, mb = has_b ? p.right_map[tid] : 0u;
     const uint32_t off_a = (ma & 0xffffu) << ES, off_b = (mb & 0xffffu) << ES;
     uint32_t wa[4], sa[4], ka[4], wb[4], sb[4], kb[4];   // store address, sign bit, keep mask of the four slots
@@ -73,12 +91,13 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
         }
         const uint32_t b = (mb >> 16) & 63u, v = b >> 4, bh = (b >> 2) & 3u, bl = b & 3u;
 #pragma unroll
-        for (uint32_t s = 0; s < 4; ++s) {   // a_hi
+        for (uint32_t i = 0; i < 4; ++i) {   // store i writes slot s = i ^ bl (a_hi): the lanes of one store instruction then spread
+            const uint32_t s = i ^ bl;       // over the slots -- with one slot per instruction they share 8 of the 32 banks
             const uint32_t y = bh ^ s;
             const uint32_t par = group_reorder_parity(s, bh) ^ (uint32_t(__builtin_popcount(s & bh & NEG_H)) & 1u);
-            wb[s] = IMG + slot_addr(bl * 16u + 4u * y + v, s);
-            sb[s] = ((par & 1u) << 31) ^ (mb & 0x80000000u);
-            kb[s] = (s & bh & Z_H) ? 0u : ~0u;
+            wb[i] = IMG + slot_addr(bl * 16u + 4u * y + v, s);
+            sb[i] = ((par & 1u) << 31) ^ (mb & 0x80000000u);
+            kb[i] = (s & bh & Z_H) ? 0u : ~0u;
         }
     }
     const T scale_a = (SCALED && has_a && p.left_scale) ? p.left_scale[tid] : T(1);
@@ -100,7 +119,6 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
     const uint32_t ooff = uint32_t(ow & 0x3fffffff) << ES, osg = (uint32_t(ow) & 0x40000000u) << 1;
     const T osc = (SCALED && p.out_scale) ? p.out_scale[comp] : T(1);
     const uint32_t ra = uint32_t(tid) * 16u, rb = IMG + uint32_t(tid) * 16u;   // this lane's operand reads
-    const bool degenerate = zero != 0u;
 
     auto apply = [&](T val, uint32_t sign, uint32_t keep) -> T {   // sign flip and (null vectors) vanishing, as bit operations
         if constexpr (F32) {
@@ -122,14 +140,16 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
 
     // ---- DEPTH items in flight per wave (register sets, the item loop unrolled DEPTH times) ----
     T pa[DEPTH], pb[DEPTH];
-    const int64_t step = gridDim.x;
-    auto fetch = [&](int64_t item, T& fa, T& fb) {
-        fa = has_a ? *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + off_a) : T(0);
-        fb = has_b ? *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.right + item * p.right_stride) + off_b) : T(0);
+    const int64_t step = int64_t(gridDim.x) * WAVES, first_item = int64_t(blockIdx.x) * WAVES + wave_id;
+    auto fetch = [&](int64_t item, T& fa, T& fb) {   // (uniform) row base + the lane's byte offset; a lane without a component re-reads element 0
+        uint32_t oa = off_a, ob = off_b;
+        asm volatile("" : "+v"(oa), "+v"(ob));
+        fa = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.left + item * p.left_stride) + oa));
+        fb = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p.right + item * p.right_stride) + ob));
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        const int64_t item = int64_t(blockIdx.x) + d * step;
+        const int64_t item = first_item + d * step;
         pa[d] = pb[d] = T(0);
         if (item < p.batch) fetch(item, pa[d], pb[d]);
     }
@@ -148,13 +168,13 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
             const int64_t nn = item + DEPTH * step;
             fetch(nn < p.batch ? nn : item, fa, fb);
         }
-        if (has_a) {
+        if (has_a) {   // (FAST: every lane)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(lds_t*)(lds + wa[j]) = degenerate ? apply(va, sa[j], ka[j]) : MM::flip(va, sa[j]);
+            for (int j = 0; j < 4; ++j) *(lds_t*)(lds + wa[j]) = apply(va, sa[j], ka[j]);
         }
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) *(lds_t*)(lds + wb[s]) = degenerate ? apply(vb, sb[s], kb[s]) : MM::flip(vb, sb[s]);
+            for (int s = 0; s < 4; ++s) *(lds_t*)(lds + wb[s]) = apply(vb, sb[s], kb[s]);
         }
         lds_barrier<64>();   // one wave: the LDS executes its instructions in order
         T av[4], bv[4];
@@ -179,32 +199,53 @@ __global__ __launch_bounds__(64) void k_gp_mfma6(DenseArgs<T> p) {
             }
         }
         typename MM::acc_t acc = {T(0), T(0), T(0), T(0)};
+#if GAAST_MFMA6_SPLIT
+        {   // two chains of two dependent instructions (a dependent 16x16x4 waits 40 cycles for its accumulator), summed at the end
+            typename MM::acc_t acc2 = {T(0), T(0), T(0), T(0)};
+            acc = MM::mma(av[0], bv[0], acc);
+            acc2 = MM::mma(av[1], bv[1], acc2);
+            acc = MM::mma(av[2], bv[2], acc);
+            acc2 = MM::mma(av[3], bv[3], acc2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] + acc2[r];
+        }
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = MM::mma(av[s], bv[s], acc);
+#endif
         // ---- the four tile elements of every component meet inside a quad ----
-        T e1 = degenerate ? apply(acc[1], su[1], ku[1]) : MM::flip(acc[1], su[1]);
-        T e2 = degenerate ? apply(acc[2], su[2], ku[2]) : MM::flip(acc[2], su[2]);
-        T e3 = degenerate ? apply(acc[3], su[3], ku[3]) : MM::flip(acc[3], su[3]);
+        T e1 = apply(acc[1], su[1], ku[1]);
+        T e2 = apply(acc[2], su[2], ku[2]);
+        T e3 = apply(acc[3], su[3], ku[3]);
         T res = acc[0];                                                              // u = 0: no sign, never vanishes
         res = res + quad_xor(e1, std::integral_constant<int, 0xB1>{});               // from lane v ^ 1
         res = res + quad_xor(e2, std::integral_constant<int, 0x4E>{});               // from lane v ^ 2
         res = res + quad_xor(e3, std::integral_constant<int, 0x1B>{});               // from lane v ^ 3
         // ---- result -> graded row ----
-        if (ook) {
+        T val = res;
+        if (SCALED) val = val * osc;
+        val = MM::flip(val, osg);
+        if constexpr (FAST) {
+            const T canon = T(0) + val;             // a zero result under a negated reordering sign stays +0.0
+            val = osg ? canon : val;
+            uint32_t oo = ooff;
+            asm volatile("" : "+v"(oo));
+            __builtin_nontemporal_store(val, reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(p.out + item * p.out_stride) + oo));
+        } else if (ook) {
             T* q = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(p.out + item * p.out_stride) + ooff);
-            T val = res;
-            if (SCALED) val = val * osc;
-            val = MM::flip(val, osg);
-            if (osg && !p.beta) val = T(0) + val;   // a zero result under a negated reordering sign stays +0.0
+            if (osg && !p.beta) val = T(0) + val;
             *q = p.beta ? *q + val : val;
         }
         lds_barrier<64>();   // the images are rewritten by the next item
     };
-    for (int64_t item = blockIdx.x; item < p.batch; item += DEPTH * step) {
+    int64_t item = first_item;
+    for (; item + (DEPTH - 1) * step < p.batch; item += DEPTH * step) {   // DEPTH items per round: straight-line code
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (item + d * step < p.batch) one_item(item + d * step, pa[d], pb[d]);
+        for (int d = 0; d < DEPTH; ++d) one_item(item + d * step, pa[d], pb[d]);
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (item + d * step < p.batch) one_item(item + d * step, pa[d], pb[d]);
 }
 
 }  // namespace gaast

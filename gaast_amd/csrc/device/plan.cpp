@@ -144,9 +144,15 @@ struct Lowering {
                     map.push_back(uint32_t(r.offset(k) + i) | (uint32_t(in.offset(k) + i) << 16));
             }
             if (map.empty()) return;
-            Step& s = emit(Step::AXPY, res, "add_grades_from[input " + std::to_string(nd.input_slot) + "]");
+            // the first writer of a fresh buffer that covers every component of it: the zero fill is folded into the copy
+            // (res = 0.0 + in: init_null_mv then `*r = *r + i`, graded.rs:74) -- one launch and one pass over res less
+            const auto fr = fresh.find(key(res));
+            const bool covers = fr != fresh.end() && !(plan.flags & GAAST_FLAG_NO_FUSION) && int64_t(map.size()) == r.row_len;
+            if (covers) removed[size_t(fr->second)] = 1;
+            Step& s = emit(Step::AXPY, res, std::string(covers ? "copy_grades_from" : "add_grades_from") + "[input " + std::to_string(nd.input_slot) + "]");
             s.a = BufRef{BufKind::INPUT, nd.input_slot};
             s.u32_a = std::move(map);
+            s.beta = covers ? 0 : 1;
             touch(res);
             return;
         }
@@ -829,6 +835,33 @@ struct Lowering {
                 }
                 *full = map.size() == (size_t(1) << n2);
                 *contig = seq && map.size() % 4 == 0 && !map.empty();
+                if (s.use_mfma6 && *full) {
+                    // k_gp_mfma6: lane q moves the component of entry q into its four image slots.  Entries are dealt to lanes so
+                    // that the lanes sharing an LDS cycle of a store hit different banks (row order: 73 % of the LDS cycles were
+                    // conflicts, profiles/r04_gp6f32_pmc_first_version.csv).  blade = (top2 | hi2 | lo2) = (u, ah, al) / (v, bh, bl):
+                    //   f32 (32 lanes per cycle): A: bank = 16 (al ^ kq)_0 + 4 u + ah    -> group = al_1;       B (slot order
+                    //        rotated by bl in the kernel): bank = 16 (bh ^ s)_0 + 4 v + s -> group = bh_1
+                    //   f64 (16 lanes per cycle, 8-byte units mod 16): A: (u_0, al ^ kq, ah_0) -> group = (u_1, ah_1);  B: (v, bh_0, bl_0)
+                    //        -> group = (bh_1, bl_1)
+                    const bool f32 = plan.dtype == GAAST_F32;
+                    auto lane_of = [&](uint32_t blade) -> uint32_t {
+                        const uint32_t t = blade >> 4, h = (blade >> 2) & 3u, l = blade & 3u;
+                        if (!right) return f32 ? ((l >> 1) << 5) | ((l & 1u) << 4) | (t << 2) | h
+                                               : ((((t >> 1) << 1) | (h >> 1)) << 4) | ((t & 1u) << 3) | (l << 1) | (h & 1u);
+                        return f32 ? ((h >> 1) << 5) | ((h & 1u) << 4) | (t << 2) | l
+                                   : ((((h >> 1) << 1) | (l >> 1)) << 4) | (t << 2) | ((h & 1u) << 1) | (l & 1u);
+                    };
+                    std::vector<uint32_t> m2(map.size());
+                    std::vector<double> s2(scale.size());
+                    for (size_t e = 0; e < map.size(); ++e) {
+                        const uint32_t q = lane_of((map[e] >> 16) & 63u);
+                        m2[q] = map[e];
+                        s2[q] = scale[e];
+                    }
+                    map.swap(m2);
+                    scale.swap(s2);
+                    *contig = 0;
+                }
                 if (s.use_mfma7 && *full) {
                     // k_gp_mfma7 moves ONE component per lane and load (entry q = load * 64 + lane), so the entries can be dealt
                     // to lanes by LDS bank: the lanes that share an LDS cycle of a store (f32: 32 lanes, bank = position mod 32;
@@ -1117,7 +1150,7 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
             break;
         }
         case Step::AXPY:
-            for (uint32_t m : s.u32_a) misc.push_back(mop(uop::ADD, rb + (m & 0xffffu), uint32_t(base_of(s.a)) + (m >> 16)));
+            for (uint32_t m : s.u32_a) misc.push_back(mop(s.beta ? uop::ADD : uop::COPY, rb + (m & 0xffffu), uint32_t(base_of(s.a)) + (m >> 16)));   // (COPY: the zero fill folded in)
             push_misc(misc);
             break;
         case Step::FLIP:
@@ -1379,7 +1412,7 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
             case Step::AXPY:
                 for (uint32_t m : s.u32_a) {
                     const std::string d = var(rb + (m & 0xffffu));
-                    src += "  " + d + " = " + d + " + " + var(uint32_t(base_of(s.a)) + (m >> 16)) + ";\n";
+                    src += "  " + d + " = " + (s.beta ? d : std::string("T(0)")) + " + " + var(uint32_t(base_of(s.a)) + (m >> 16)) + ";\n";
                 }
                 break;
             case Step::FLIP:
@@ -1516,6 +1549,122 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
         }
         src += "}\n";
         f.jit_threads = threads;
+        f.jit_source = std::move(src);
+    } else if (!(plan.flags & GAAST_FLAG_NO_JIT) && interp_ok && !plan.has_explog && entries <= 2048 &&
+               size_t(slab | 1) * elem * 64 + 64 <= kLdsBytes) {
+        // ---- MEDIUM programs (round 4): the slab is beyond the registers of the specialised kernel above (160 / 200 elements) but the
+        // program is short -- the versor inverse a.rev() * a.norm_sq().sinv() at n = 8 (slab 259, 256 comp-muls), the projection KAT at
+        // n = 12 (slab 171) -- and used to run on the LDS interpreter (wave-uniform micro-op decode: 0.16 / 0.10 of the HBM roof).  The
+        // same plan as straight-line code over slabs that STAY IN LDS: a workgroup of eight waves owns the slabs of 64 items (item i at
+        // i * stride elements, stride odd: the lanes of a wave touch 64 different banks at any slab offset), lane <-> item, and the
+        // independent rows of every arm are dealt to the waves, least-loaded first -- exactly the interpreter's schedule, with the
+        // decode done by hiprtc: offsets are immediates of the LDS instructions, signs are operators.  Same statements, same order.
+        std::string src;
+        char buf[256];
+        const char* ty = plan.dtype == GAAST_F32 ? "float" : "double";
+        auto lit = [&](double c) {
+            std::snprintf(buf, sizeof(buf), plan.dtype == GAAST_F32 ? "%af" : "%a", plan.dtype == GAAST_F32 ? double(float(c)) : c);
+            return std::string(buf);
+        };
+        const int stride = slab | 1;
+        constexpr int W = 8;   // waves per workgroup
+        auto at = [&](uint32_t i) { return "my[" + std::to_string(i) + "]"; };
+        src += std::string("typedef ") + ty + " T;\n";
+        src += "extern \"C\" __global__ __launch_bounds__(512) void gaast_jit(";
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i)
+            src += "const T* __restrict__ in" + std::to_string(i) + ", long long s" + std::to_string(i) + ", ";
+        src += "T* __restrict__ out, long long so, long long batch) {\n";
+        src += "  __shared__ T slab[" + std::to_string(64 * stride) + "];\n";
+        src += "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n";
+        src += "  const long long item0 = blockIdx.x * 64LL;\n";
+        src += "  const int nitems = int(batch - item0 < 64 ? batch - item0 : 64);\n";
+        // inputs: element e = item * len + c of the flattened range, consecutive threads read consecutive elements (coalesced when the
+        // rows are contiguous); rows beyond the batch are zero
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const Step::FusedInput& fi = f.fused_inputs[i];
+            const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
+            const std::string I = std::to_string(i), L = std::to_string(len);
+            src += "#pragma unroll 4\n  for (int e = tid; e < " + std::to_string(64 * len) + "; e += 512) { const int i2 = e / " + L + ", c = e - i2 * " + L +
+                   "; T v = i2 < nitems ? in" + I + "[(item0 + i2) * s" + I + " + c] : T(0); slab[i2 * " + std::to_string(stride) + " + " +
+                   std::to_string(fi.base) + " + c] = " + (fi.canon ? "T(0) + v" : "v") + "; }\n";
+        }
+        src += "  T* const my = slab + lane * " + std::to_string(stride) + ";\n";
+        src += "  __syncthreads();\n";
+        for (const Step& s : plan.steps) {
+            const uint32_t rb = uint32_t(base_of(s.res));
+            // the independent pieces of this arm, each a (cost, statements) pair, dealt to the waves least-loaded first
+            std::vector<std::pair<uint64_t, std::string>> pieces;
+            auto elementwise = [&](const std::vector<std::string>& stmts) {   // chunks of up to 16 statements
+                for (size_t i = 0; i < stmts.size(); i += 16) {
+                    std::string blk;
+                    for (size_t k = i; k < std::min(stmts.size(), i + 16); ++k) blk += "      " + stmts[k] + "\n";
+                    pieces.emplace_back(std::min<size_t>(16, stmts.size() - i), blk);
+                }
+            };
+            std::vector<std::string> st;
+            switch (s.kind) {
+            case Step::ZERO:
+                for (int64_t o = 0; o < layout_of(s.res).row_len; ++o) st.push_back(at(rb + uint32_t(o)) + " = T(0);");
+                elementwise(st);
+                break;
+            case Step::AXPY:
+                for (uint32_t m : s.u32_a) {
+                    const std::string d = at(rb + (m & 0xffffu));
+                    st.push_back(d + " = " + (s.beta ? d : std::string("T(0)")) + " + " + at(uint32_t(base_of(s.a)) + (m >> 16)) + ";");
+                }
+                elementwise(st);
+                break;
+            case Step::FLIP:
+                for (uint32_t o : s.u32_a) st.push_back(at(rb + o) + " = -" + at(rb + o) + ";");
+                elementwise(st);
+                break;
+            case Step::SUNARY: {
+                const std::string d = at(rb + uint32_t(s.sunary_off));
+                st.push_back(s.sunary_op == 0 ? d + " = T(1) / " + d + ";"
+                                              : d + (plan.dtype == GAAST_F32 ? " = __builtin_sqrtf(" : " = __builtin_sqrt(") + d + ");");
+                elementwise(st);
+                break;
+            }
+            case Step::PRODUCT_CSR: {
+                const uint32_t lb = uint32_t(base_of(s.a, s.canon_a)), rrb = uint32_t(base_of(s.b, s.canon_b));
+                for (size_t row = 0; row + 1 < s.u32_a.size(); ++row) {
+                    const std::string d = at(rb + s.u32_b[row]);
+                    std::string blk = "      { T acc = " + (s.beta ? d : std::string("T(0)")) + ";\n";
+                    for (uint32_t e = s.u32_a[row]; e < s.u32_a[row + 1]; ++e) {
+                        const std::string prod = "(" + at(lb + (s.u32_c[e] & 0xffffu)) + " * " + at(rrb + (s.u32_c[e] >> 16)) + ")";
+                        const double c = s.coeff[e];
+                        blk += c == 1.0 ? "        acc = acc + " + prod + ";\n"
+                               : c == -1.0 ? "        acc = acc - " + prod + ";\n"
+                                           : "        acc = acc + " + prod + " * T(" + lit(c) + ");\n";
+                    }
+                    blk += "        " + d + " = acc; }\n";
+                    pieces.emplace_back(uint64_t(s.u32_a[row + 1] - s.u32_a[row]) + 2, blk);
+                }
+                break;
+            }
+            default: return false;
+            }
+            std::vector<std::string> per_wave(W);
+            std::vector<uint64_t> load(W, 0);
+            for (const auto& pc : pieces) {
+                int g = 0;
+                for (int i = 1; i < W; ++i)
+                    if (load[size_t(i)] < load[size_t(g)]) g = i;
+                per_wave[size_t(g)] += pc.second;
+                load[size_t(g)] += pc.first;
+            }
+            src += "  switch (wave) {\n";
+            for (int g = 0; g < W; ++g)
+                if (!per_wave[size_t(g)].empty()) src += "    case " + std::to_string(g) + ": {\n" + per_wave[size_t(g)] + "    } break;\n";
+            src += "    default: break;\n  }\n  __syncthreads();\n";
+        }
+        const int out_len = int(plan.out_layout.row_len);
+        src += "#pragma unroll 4\n  for (int e = tid; e < " + std::to_string(64 * out_len) + "; e += 512) { const int i2 = e / " + std::to_string(out_len) +
+               ", c = e - i2 * " + std::to_string(out_len) + "; if (i2 < nitems) out[(item0 + i2) * so + c] = slab[i2 * " + std::to_string(stride) +
+               " + " + std::to_string(out_base) + " + c]; }\n";
+        src += "}\n";
+        f.jit_threads = 512;
+        f.jit_items = 64;
         f.jit_source = std::move(src);
     }
     f.fused_slab = slab;
@@ -1705,11 +1854,18 @@ static void chain_sparse_into_dense(Plan& plan) {
 //     (acc + (+0.0) would turn a -0.0 accumulator of a beta = 1 list into +0.0);
 //   * reference order and roundings: bit-identical to the two-launch plan and to the oracle.
 // ---------------------------------------------------------------------------------------------------------------------
-static void make_chain_jit(const Plan& plan, Step& c, const Step& w, int64_t l1, int64_t r1, int64_t mid, int64_t r2, int alias, int side,
-                           bool covered) {
+// wp == nullptr: a SINGLE list with few long rows (rows2 x IPB lanes instead of rows2; k_product_ell gives a row to a thread): the
+// left operand plays the staged "mid" row (l1 = r1 = 0, mid = its length), the right one is list 2's own operand r2 (alias 0,
+// side 1).  init_off (single list only): acc starts from 0.0 + init[row's offset] -- a covering copy_grades_from of an input
+// folded into the list that accumulates onto it ((a + b * c).g(2): one launch).
+static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1, int64_t r1, int64_t mid, int64_t r2, int alias, int side,
+                           bool covered, const std::vector<uint32_t>* init_off = nullptr) {
     if (plan.flags & (GAAST_FLAG_NO_JIT | GAAST_FLAG_DEBUG_JIT_FAILS)) return;
+    const bool single = wp == nullptr;
+    static const Step no_list;
+    const Step& w = single ? no_list : *wp;
     const int64_t esz = plan.dtype == GAAST_F32 ? 4 : 8;
-    const int64_t neg_len = std::min(l1, r1);
+    const int64_t neg_len = single ? 0 : std::min(l1, r1);
     const bool neg_is_left = l1 < r1;
     // layout of an item in LDS (elements): list 2's own operand first (its offsets have 15 bits), then the rest
     int64_t off_l1 = 0, off_r1 = 0, off_neg, off_mid, off_r2 = -1, cur = 0;
@@ -1725,18 +1881,41 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step& w, int64_t l1,
     if ((off_other + other_len) * esz > 32768 || stride * esz > 65535) return;
     const int64_t rows1 = int64_t(w.u32_b.size()), rows2 = int64_t(c.u32_b.size());
     const int64_t w1 = w.ell_width, w2 = c.ell_width;
-    if (rows1 <= 0 || rows2 <= 0 || w1 <= 0 || w2 <= 0 || w1 > 32) return;   // (list 1's operands of a row are all in flight at once)
+    if (rows2 <= 0 || w2 <= 0) return;
+    if (!single && (rows1 <= 0 || w1 <= 0 || w1 > 32)) return;   // (list 1's operands of a row are all in flight at once)
     // items per workgroup: a power of two up to 32 (the lanes of an LDS access group), as many as the LDS holds
     int64_t ipb = 32;
-    const int64_t lds_cap = int64_t(kLdsBytes) - 2048;
-    while (ipb > 1 && ipb * stride * esz > lds_cap) ipb >>= 1;
+    const int64_t lds_cap = int64_t(kLdsBytes);
+    while (ipb > 1 && ipb * stride * esz > lds_cap - 4096) ipb >>= 1;
     if (ipb < 2) return;
-    int64_t threads = (rows2 * ipb + 63) / 64 * 64;   // list 2 (few long rows) in one pass
-    threads = std::max<int64_t>(256, std::min<int64_t>(1024, threads));
     const int64_t w1p = (w1 + 3) & ~int64_t(3), w2p = (w2 + 3) & ~int64_t(3);
+    // The tables ride in LDS when they fit beside the items (broadcast reads; from global memory every lane would get its own
+    // copy of the words through the vector cache: 16 cycles of its return path per 16-byte load and wave).
+    //   list 2: WIDE entries (8 bytes: [15:0] mid | [31:16] other, then the sign bit alone) cost two vector instructions less per
+    //           term than narrow ones ([15:0] mid | [30:16] other | [31] sign) -- taken when they fit;
+    //   list 1: rows padded to quads (16-byte reads) when that fits, else unpadded rows (4-byte reads), else global memory.
+    const int64_t items_bytes = (ipb * stride * esz + 15) / 16 * 16;
+    int64_t used = items_bytes;
+    int ent2_mode;   // 0: narrow, global; 1: narrow, LDS; 2: wide, LDS
+    if (used + rows2 * w2p * 8 <= lds_cap) ent2_mode = 2, used += rows2 * w2p * 8;
+    else if (used + rows2 * w2p * 4 <= lds_cap) ent2_mode = 1, used += rows2 * w2p * 4;
+    else ent2_mode = 0;
+    const int64_t ent2_at = items_bytes;
+    int ent1_mode;   // 0: padded rows, global; 1: unpadded rows, LDS; 2: padded rows, LDS
+    const int64_t ent1_at = used;
+    if (used + rows1 * w1p * 4 <= lds_cap) ent1_mode = 2, used += rows1 * w1p * 4;
+    else if (used + rows1 * w1 * 4 <= lds_cap) ent1_mode = 1, used += rows1 * w1 * 4;
+    else ent1_mode = 0;
+    used = (used + 15) / 16 * 16;
+    // one workgroup per CU (the usual case from n = 9 on): 512 threads -- list 1 and the staging have work for all of them, list 2
+    // (few long rows) for rows2 * ipb lanes; two or more workgroups per CU: 256 threads each
+    int64_t threads = 2 * used <= lds_cap ? 256 : 512;
+    threads = std::max<int64_t>(threads, std::min<int64_t>(1024, (rows2 * ipb + 63) / 64 * 64));
+    const int64_t w1s = ent1_mode == 1 ? w1 : w1p;   // words per row of list 1's table
     // tables
-    c.cj_ent1.assign(size_t(rows1 * w1p), 0u);
+    c.cj_ent1.assign(size_t(rows1 * w1s), 0u);
     c.cj_pos1.resize(size_t(rows1));
+    if (init_off) c.cj_pos1 = *init_off;   // (a single list has no row positions: the slot carries the offsets of the folded copy)
     for (int64_t row = 0; row < rows1; ++row) {
         c.cj_pos1[size_t(row)] = uint32_t((off_mid + int64_t(w.u32_b[size_t(row)])) * esz);
         for (int64_t t = 0; t < w1; ++t) {
@@ -1745,24 +1924,24 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step& w, int64_t l1,
             const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;   // bytes, from the operand rows
             const int64_t la = ((neg && neg_is_left) ? off_neg : off_l1) * esz + lo;
             const int64_t ra = ((neg && !neg_is_left) ? off_neg : off_r1) * esz + ro;
-            c.cj_ent1[size_t(row * w1p + t)] = uint32_t(la) | (uint32_t(ra) << 16);
+            c.cj_ent1[size_t(row * w1s + t)] = uint32_t(la) | (uint32_t(ra) << 16);
         }
     }
-    c.cj_ent2.assign(size_t(rows2 * w2p), 0u);
+    const int64_t wpt2 = ent2_mode == 2 ? 2 : 1;   // words per term
+    c.cj_ent2.assign(size_t(rows2 * w2p * wpt2), 0u);
     c.cj_out2 = c.u32_b;
     for (int64_t row = 0; row < rows2; ++row)
         for (int64_t t = 0; t < w2; ++t) {
             const uint32_t e = c.u32_c[size_t(t * rows2 + row)];
             const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;
             const int64_t ma = off_mid * esz + (side == 1 ? lo : ro), oa = off_other * esz + (side == 1 ? ro : lo);
-            c.cj_ent2[size_t(row * w2p + t)] = uint32_t(ma) | (uint32_t(oa) << 16) | (e & 0x80000000u);
+            if (ent2_mode == 2) {
+                c.cj_ent2[size_t((row * w2p + t) * 2)] = uint32_t(ma) | (uint32_t(oa) << 16);
+                c.cj_ent2[size_t((row * w2p + t) * 2 + 1)] = e & 0x80000000u;
+            } else {
+                c.cj_ent2[size_t(row * w2p + t)] = uint32_t(ma) | (uint32_t(oa) << 16) | (e & 0x80000000u);
+            }
         }
-    // the tables ride in LDS when they fit beside the items (list 2's first: its words are read once per term by few lanes);
-    // a table that does not fit is read from global memory (L1 / L2), a quad of entries per 16-byte load
-    const int64_t items_bytes = (ipb * stride * esz + 15) / 16 * 16;
-    const int64_t ent2_bytes = rows2 * w2p * 4, ent1_bytes = rows1 * w1p * 4;
-    const bool ent2_lds = items_bytes + ent2_bytes <= int64_t(kLdsBytes);
-    const bool ent1_lds = items_bytes + (ent2_lds ? ent2_bytes : 0) + ent1_bytes <= int64_t(kLdsBytes);
     // source
     std::string src;
     auto def = [&](const char* name, int64_t v) { src += std::string("#define ") + name + " " + std::to_string(v) + "\n"; };
@@ -1771,103 +1950,252 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step& w, int64_t l1,
     def("L1", l1); def("R1", r1); def("R2", alias ? 0 : r2); def("MID", mid); def("NEGLEN", neg_len); def("NEG_IS_LEFT", neg_is_left ? 1 : 0);
     def("OFF_L1", off_l1 * esz); def("OFF_R1", off_r1 * esz); def("OFF_NEG", off_neg * esz); def("OFF_MID", off_mid * esz);
     def("OFF_R2", (alias ? 0 : off_r2) * esz); def("HAS_R2", alias ? 0 : 1);
-    def("ROWS1", rows1); def("W1", w1); def("W1P", w1p); def("ROWS2", rows2); def("W2", w2); def("W2P", w2p);
+    def("ROWS1", rows1); def("W1", w1); def("W1S", w1s); def("ROWS2", rows2); def("W2", w2); def("W2P", w2p);
     def("CANON_L1", w.canon_a); def("CANON_R1", w.canon_b); def("CANON_R2", side == 1 ? c.canon_b : c.canon_a);
-    def("CANON_MID", side == 1 ? c.canon_a : c.canon_b); def("COVERED", covered ? 1 : 0); def("BETA", c.beta);
-    def("ITEMS_BYTES", items_bytes); def("ENT2_LDS", ent2_lds ? 1 : 0); def("ENT1_LDS", ent1_lds ? 1 : 0);
-    def("ENT2_AT", items_bytes); def("ENT1_AT", items_bytes + (ent2_lds ? ent2_bytes : 0));
-    def("SMEM_BYTES", items_bytes + (ent2_lds ? ent2_bytes : 0) + (ent1_lds ? ent1_bytes : 0));
+    def("CANON_MID", side == 1 ? c.canon_a : c.canon_b); def("COVERED", covered ? 1 : 0); def("BETA", init_off ? 0 : c.beta);
+    def("SINGLE", single ? 1 : 0); def("INIT_SRC", init_off ? 1 : 0);
+    bool pos1_linear = true;   // row k of list 1 is component k of the mid row (the usual case): no table, no load
+    for (int64_t row = 0; row < rows1; ++row) pos1_linear = pos1_linear && int64_t(w.u32_b[size_t(row)]) == row;
+    def("POS1_LINEAR", pos1_linear ? 1 : 0);
+    def("PASSES2", (rows2 + threads / ipb - 1) / (threads / ipb));   // rows of list 2 per thread
+    // terms of list 2 in flight per register set: the registers of two waves per SIMD (512 threads) hold 8 f64 / 16 f32 terms twice; more
+    // threads (a single list with many rows x items), fewer registers each
+    def("TB", (plan.dtype == GAAST_F32 ? 16 : 8) / (threads > 512 ? 2 : 1));
+    def("ENT2_MODE", ent2_mode); def("ENT1_MODE", ent1_mode); def("ENT2_AT", ent2_at); def("ENT1_AT", ent1_at); def("SMEM_BYTES", used);
     src += R"JIT(
 typedef unsigned int u32;
 typedef unsigned long long u64;
-struct __attribute__((aligned(16))) q4 { u32 x, y, z, w; };
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef T VT __attribute__((ext_vector_type(16 / ESZ)));
+#define EPC (16 / ESZ)
 #if F64
 #define ONE_HI 0x3ff00000u
-__device__ __forceinline__ T sgn_of(u32 e, u32 one_hi) {
-    u32 hi;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(e), "s"(0x80000000u), "v"(one_hi));   // +-1.0: the high word; the low word is 0
-    return __builtin_bit_cast(double, ((u64)hi) << 32);
-}
+__device__ __forceinline__ T with_hi(T v, u32 hi) { return __builtin_bit_cast(double, (u64(hi) << 32) | (__builtin_bit_cast(u64, v) & 0xffffffffull)); }
+__device__ __forceinline__ u32 hi_of(T v) { return u32(__builtin_bit_cast(u64, v) >> 32); }
+__device__ __forceinline__ T pm_one(u32 hi) { return __builtin_bit_cast(double, u64(hi) << 32); }
 #define FMA(a, b, c) __builtin_fma(a, b, c)
 #else
 #define ONE_HI 0x3f800000u
-__device__ __forceinline__ T sgn_of(u32 e, u32 one_hi) {
-    u32 hi;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(e), "s"(0x80000000u), "v"(one_hi));
-    return __builtin_bit_cast(float, hi);
-}
+__device__ __forceinline__ T with_hi(T v, u32 hi) { return __builtin_bit_cast(float, hi); }
+__device__ __forceinline__ u32 hi_of(T v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ T pm_one(u32 hi) { return __builtin_bit_cast(float, hi); }
 #define FMA(a, b, c) __builtin_fmaf(a, b, c)
 #endif
-#define LDS(addr) (*(const T*)(smem + (addr)))
-__device__ __forceinline__ u32 word_of(const q4& e4, int t) { return (t & 3) == 0 ? e4.x : (t & 3) == 1 ? e4.y : (t & 3) == 2 ? e4.z : e4.w; }
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+#define LDS(addr) (*(const __attribute__((address_space(3))) T*)(smem + (addr)))
 
 // operand rows of the group's items, element e = item * LEN + c of the flattened range; rows beyond the batch are zero
 template <int LEN, int CANON, int OFF, int NEGOFF>
-__device__ __forceinline__ void stage(unsigned char* smem, const T* __restrict__ src, long long stride, long long item0, int nitems, int tid) {
+__device__ __forceinline__ void put(lds_u8* smem, int e, T v) {
+    const int i2 = e / LEN, c = e - i2 * LEN;
+    if (CANON) v = T(0) + v;                                      // init_null_mv + add_grades_from: 0.0 + x (eval.rs:27-31)
+    *(__attribute__((address_space(3))) T*)(smem + i2 * STRIDE_B + OFF + c * ESZ) = v;
+    if (NEGOFF >= 0) *(__attribute__((address_space(3))) T*)(smem + i2 * STRIDE_B + NEGOFF + c * ESZ) = -v;
+}
+template <int LEN, int CANON, int OFF, int NEGOFF>
+__device__ __forceinline__ void stage(lds_u8* smem, const T* __restrict__ src, long long stride, long long item0, int nitems, int tid) {
     constexpr int TOTAL = IPB * LEN;
 #pragma unroll 4
     for (int e = tid; e < TOTAL; e += NT) {
         const int i2 = e / LEN, c = e - i2 * LEN;
-        T v = i2 < nitems ? src[(item0 + i2) * stride + c] : T(0);
-        if (CANON) v = T(0) + v;                                  // init_null_mv + add_grades_from: 0.0 + x (eval.rs:27-31)
-        *(T*)(smem + i2 * STRIDE_B + OFF + c * ESZ) = v;
-        if (NEGOFF >= 0) *(T*)(smem + i2 * STRIDE_B + NEGOFF + c * ESZ) = -v;
+        put<LEN, CANON, OFF, NEGOFF>(smem, e, i2 < nitems ? src[(item0 + i2) * stride + c] : T(0));
     }
 }
+// ... the same rows as 16-byte pieces through registers: issued for the NEXT group while the current one is evaluated (contiguous,
+// 16-byte aligned rows of a full group; anything else takes stage())
+template <int LEN>
+struct Pre {
+    static constexpr int NCH = IPB * LEN / EPC, CPT = (NCH + NT - 1) / NT;
+    VT v[CPT];
+    __device__ __forceinline__ void issue(const T* __restrict__ src, long long item0, int tid) {
+        const VT* s16 = (const VT*)(src + item0 * LEN);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (tid + k * NT < NCH) v[k] = __builtin_nontemporal_load(s16 + tid + k * NT);
+    }
+    template <int CANON, int OFF, int NEGOFF>
+    __device__ __forceinline__ void commit(lds_u8* smem, int tid) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (tid + k * NT < NCH) {
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) put<LEN, CANON, OFF, NEGOFF>(smem, (tid + k * NT) * EPC + j, v[k][j]);
+            }
+    }
+};
 
 extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict__ l1, long long s_l1, const T* __restrict__ r1, long long s_r1,
                                                               const T* __restrict__ r2, long long s_r2, T* __restrict__ out, long long s_out,
                                                               const u32* __restrict__ ent1, const u32* __restrict__ pos1,
-                                                              const u32* __restrict__ ent2, const u32* __restrict__ out2, long long batch) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+                                                              const u32* __restrict__ ent2, const u32* __restrict__ out2, long long batch,
+                                                              const T* __restrict__ init, long long s_init) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    lds_u8* smem = (lds_u8*)smem_raw;
     const int tid = threadIdx.x;
     const int it = tid & (IPB - 1), sub = tid / IPB;
     const u32 base = u32(it) * STRIDE_B;
     u32 one_hi = ONE_HI;
     asm volatile("" : "+v"(one_hi));   // a vector register (the and-or takes one scalar operand)
     // the tables, once per (persistent) workgroup
-#if ENT2_LDS
-    for (int e = tid; e < ROWS2 * W2P / 4; e += NT) ((q4*)(smem + ENT2_AT))[e] = ((const q4*)ent2)[e];
-    const q4* const tab2 = (const q4*)(smem + ENT2_AT);
-#else
-    const q4* const tab2 = (const q4*)ent2;
+#if ENT2_MODE == 2
+    for (int e = tid; e < ROWS2 * W2P / 2; e += NT) ((__attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[e] = ((const u32x4*)ent2)[e];
+#elif ENT2_MODE == 1
+    for (int e = tid; e < ROWS2 * W2P / 4; e += NT) ((__attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[e] = ((const u32x4*)ent2)[e];
 #endif
-#if ENT1_LDS
-    for (int e = tid; e < ROWS1 * W1P / 4; e += NT) ((q4*)(smem + ENT1_AT))[e] = ((const q4*)ent1)[e];
-    const q4* const tab1 = (const q4*)(smem + ENT1_AT);
+#if ENT1_MODE >= 1 && !SINGLE
+    for (int e = tid; e < ROWS1 * W1S; e += NT) ((__attribute__((address_space(3))) u32*)(smem + ENT1_AT))[e] = ent1[e];
+#endif
+    // entry words: list 1, term t of `row`; list 2, the quad holding terms 4q .. 4q + 3 (narrow) / 2q, 2q + 1 (wide)
+#if !SINGLE
+    auto ent1_quad = [&](int row, int q) -> u32x4 {
+#if ENT1_MODE == 2
+        return ((const __attribute__((address_space(3))) u32x4*)(smem + ENT1_AT))[row * (W1S / 4) + q];
+#elif ENT1_MODE == 1
+        const __attribute__((address_space(3))) u32* pw = (const __attribute__((address_space(3))) u32*)(smem + ENT1_AT) + row * W1S + 4 * q;
+        u32x4 r;
+        r[0] = pw[0];
+        r[1] = 4 * q + 1 < W1 ? pw[1] : 0u;
+        r[2] = 4 * q + 2 < W1 ? pw[2] : 0u;
+        r[3] = 4 * q + 3 < W1 ? pw[3] : 0u;
+        return r;
 #else
-    const q4* const tab1 = (const q4*)ent1;
+        return ((const u32x4*)ent1)[row * (W1S / 4) + q];
+#endif
+    };
+#endif
+    auto ent2_quad = [&](int row, int q) -> u32x4 {
+#if ENT2_MODE == 2
+        return ((const __attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[row * (W2P / 2) + q];
+#elif ENT2_MODE == 1
+        return ((const __attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[row * (W2P / 4) + q];
+#else
+        return ((const u32x4*)ent2)[row * (W2P / 4) + q];
+#endif
+    };
+    u32 oo_reg[PASSES2];   // this thread's rows of list 2: their output offsets, loaded once
+#pragma unroll
+    for (int k = 0; k < PASSES2; ++k) oo_reg[k] = sub + k * NSUB < ROWS2 ? out2[sub + k * NSUB] : 0u;
+#if INIT_SRC
+    u32 io_reg[PASSES2];   // ... and where their accumulators start from: 0.0 + init[offset] (a covering copy_grades_from folded in)
+#pragma unroll
+    for (int k = 0; k < PASSES2; ++k) io_reg[k] = sub + k * NSUB < ROWS2 ? pos1[sub + k * NSUB] : 0u;
 #endif
     const long long groups = (batch + IPB - 1) / IPB;
-    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {   // persistent workgroups
-        const long long item0 = g * IPB;
-        const int nitems = int(batch - item0 < IPB ? batch - item0 : IPB);
+    // register-prefetch staging needs contiguous, 16-byte aligned rows (wave-uniform test); shared rows (stride 0), wrapped
+    // strided memory and the last, partial group take the plain loop
+    // (the memory counter is IN ORDER: a wait for any later global load would wait for the prefetched rows first, so the evaluation
+    //  issues none where it can: row positions and output offsets in registers, tables in LDS.  A table that has to stay in global
+    //  memory (n = 10: list 1's) makes the first row of list 1 wait for the prefetch -- still better than no prefetch: measured
+    //  0.214 against 0.164 G items/s at n = 10)
+#if SINGLE
+    // a single list: the left operand is the staged "mid" row (pointer l1), the right one list 2's own operand (pointer r2)
+    const bool fast = s_l1 == MID && s_r2 == R2 && ((u64)l1 & 15ull) == 0 && ((u64)r2 & 15ull) == 0 && (IPB * MID) % EPC == 0 && (IPB * R2) % EPC == 0;
+    Pre<MID> pl;
+    Pre<R2> pq;
+    auto issue = [&](long long item0) {
+        pl.issue(l1, item0, tid);
+        pq.issue(r2, item0, tid);
+    };
+    auto commit = [&]() {
+        pl.template commit<CANON_MID, OFF_MID, -1>(smem, tid);
+        pq.template commit<CANON_R2, OFF_R2, -1>(smem, tid);
+    };
+    auto stage_all = [&](long long item0, int nitems) {
+        stage<MID, CANON_MID, OFF_MID, -1>(smem, l1, s_l1, item0, nitems, tid);
+        stage<R2, CANON_R2, OFF_R2, -1>(smem, r2, s_r2, item0, nitems, tid);
+    };
+#else
+    const bool fast = s_l1 == L1 && s_r1 == R1 && ((u64)l1 & 15ull) == 0 && ((u64)r1 & 15ull) == 0 && (IPB * L1) % EPC == 0 && (IPB * R1) % EPC == 0
+#if HAS_R2
+                      && s_r2 == R2 && ((u64)r2 & 15ull) == 0 && (IPB * R2) % EPC == 0
+#endif
+        ;
+    Pre<L1> pl;
+    Pre<R1> pr;
+#if HAS_R2
+    Pre<R2> pq;
+#endif
+    auto issue = [&](long long item0) {
+        pl.issue(l1, item0, tid);
+        pr.issue(r1, item0, tid);
+#if HAS_R2
+        pq.issue(r2, item0, tid);
+#endif
+    };
+    auto commit = [&]() {
+        pl.template commit<CANON_L1, OFF_L1, (NEG_IS_LEFT ? OFF_NEG : -1)>(smem, tid);
+        pr.template commit<CANON_R1, OFF_R1, (NEG_IS_LEFT ? -1 : OFF_NEG)>(smem, tid);
+#if HAS_R2
+        pq.template commit<CANON_R2, OFF_R2, -1>(smem, tid);
+#endif
+    };
+    auto stage_all = [&](long long item0, int nitems) {
         stage<L1, CANON_L1, OFF_L1, (NEG_IS_LEFT ? OFF_NEG : -1)>(smem, l1, s_l1, item0, nitems, tid);
         stage<R1, CANON_R1, OFF_R1, (NEG_IS_LEFT ? -1 : OFF_NEG)>(smem, r1, s_r1, item0, nitems, tid);
 #if HAS_R2
         stage<R2, CANON_R2, OFF_R2, -1>(smem, r2, s_r2, item0, nitems, tid);
 #endif
-#if !COVERED
-        for (int e = tid; e < IPB * MID; e += NT) *(T*)(smem + (e / MID) * STRIDE_B + OFF_MID + (e % MID) * ESZ) = T(0);
+    };
+#endif
+    long long g = blockIdx.x;
+    if (g >= groups) return;
+    {
+        const long long item0 = g * IPB;
+        const int nitems = int(batch - item0 < IPB ? batch - item0 : IPB);
+        if (fast && nitems == IPB) {
+            issue(item0);
+            commit();
+        } else {
+            stage_all(item0, nitems);
+        }
+    }
+    for (;;) {   // persistent workgroups
+        const long long item0 = g * IPB;
+        const int nitems = int(batch - item0 < IPB ? batch - item0 : IPB);
+        const long long gn = g + gridDim.x;
+        const bool more = gn < groups;
+        const int nnext = more ? int(batch - gn * IPB < IPB ? batch - gn * IPB : IPB) : 0;
+        const bool pre_next = fast && more && nnext == IPB;
+#if !COVERED && !SINGLE
+        for (int e = tid; e < IPB * MID; e += NT) *(__attribute__((address_space(3))) T*)(smem + (e / MID) * STRIDE_B + OFF_MID + (e % MID) * ESZ) = T(0);
 #endif
         __syncthreads();
+#if BETA
+        T acc0[PASSES2];   // list 2 adds into what another arm left in `out`: read BEFORE the prefetch is issued (in-order counter)
+#pragma unroll
+        for (int k = 0; k < PASSES2; ++k) acc0[k] = (sub + k * NSUB < ROWS2 && it < nitems) ? out[(item0 + it) * s_out + oo_reg[k]] : T(0);
+#elif INIT_SRC
+        T acc0[PASSES2];   // ... or onto a copy of an input's grades, made here: 0.0 + x (graded.rs:195-201 then :74)
+#pragma unroll
+        for (int k = 0; k < PASSES2; ++k) acc0[k] = T(0) + ((sub + k * NSUB < ROWS2 && it < nitems) ? init[(item0 + it) * s_init + io_reg[k]] : T(0));
+#endif
+        if (pre_next) issue(gn * IPB);   // in flight while this group is evaluated
         // ---- list 1 -> mid (eval.rs:77-83 into the fresh cache buffer of eval.rs:21-33): the operands of row k + 1 are in
         // flight while row k's chain is evaluated (two register sets, the loop unrolled by two: no copies) ----
+#if !SINGLE
         {
             T la[W1], ra[W1], lb[W1], rb[W1];
             auto load1 = [&](T (&lv)[W1], T (&rv)[W1], int row) {
 #pragma unroll
-                for (int t = 0; t < W1; ++t) {
-                    const u32 e = word_of(tab1[row * (W1P / 4) + t / 4], t);
-                    lv[t] = LDS(base + (e & 0xffffu));
-                    rv[t] = LDS(base + (e >> 16));
+                for (int q = 0; q < (W1 + 3) / 4; ++q) {
+                    const u32x4 e4 = ent1_quad(row, q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j < W1) {
+                            lv[4 * q + j] = LDS(base + (e4[j] & 0xffffu));
+                            rv[4 * q + j] = LDS(base + (e4[j] >> 16));
+                        }
                 }
             };
             auto sum1 = [&](const T (&lv)[W1], const T (&rv)[W1], int row) {
                 T acc = T(0);
 #pragma unroll
                 for (int t = 0; t < W1; ++t) acc = acc + lv[t] * rv[t];      // (l * r) * (+-1) then +=: the sign rides in the image
-                *(T*)(smem + base + pos1[row]) = CANON_MID ? T(0) + acc : acc;
+#if POS1_LINEAR
+                *(__attribute__((address_space(3))) T*)(smem + base + OFF_MID + row * ESZ) = CANON_MID ? T(0) + acc : acc;
+#else
+                *(__attribute__((address_space(3))) T*)(smem + base + pos1[row]) = CANON_MID ? T(0) + acc : acc;
+#endif
             };
             constexpr int LAST1 = ROWS1 - 1;
             int row = sub;
@@ -1882,27 +2210,62 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             }
         }
         __syncthreads();
-        // ---- list 2: (mid, other operand) -> out; sixteen terms' operands in flight while the previous sixteen are summed ----
-#pragma nounroll
-        for (int row = sub; row < ROWS2; row += NSUB) {
-            const u32 oo = out2[row];
-            T acc = (BETA && it < nitems) ? out[(item0 + it) * s_out + oo] : T(0);
-            const q4* ep = tab2 + row * (W2P / 4);
-            constexpr int NB = W2 / 16;                  // batches of sixteen terms
-            T ma[16], oa[16], sa[16], mb[16], ob[16], sb[16];
-            auto load2 = [&](T (&mv)[16], T (&ov)[16], T (&sg)[16], int b) {
+#endif
+        // ---- list 2: (mid, other operand) -> out; TB terms' operands in flight while the previous TB are summed ----
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const u32 e = word_of(ep[4 * b + t / 4], t);
-                    mv[t] = LDS(base + (e & 0xffffu));
-                    ov[t] = LDS(base + ((e >> 16) & 0x7fffu));
-                    sg[t] = sgn_of(e, one_hi);
+        for (int pass = 0; pass < PASSES2; ++pass) {
+            const int row = sub + pass * NSUB;
+            if (row >= ROWS2) break;
+            const u32 oo = oo_reg[pass];
+#if BETA || INIT_SRC
+            T acc = acc0[pass];
+#else
+            T acc = T(0);
+#endif
+            constexpr int NB = W2 / TB;                  // batches of TB terms
+#if ENT2_MODE == 2
+            T ma[TB], oa[TB], mb[TB], ob[TB];
+            u32 sa[TB], sb[TB];
+            auto load2 = [&](T (&mv)[TB], T (&ov)[TB], u32 (&sg)[TB], int b) {
+#pragma unroll
+                for (int q = 0; q < TB / 2; ++q) {
+                    const u32x4 e4 = ent2_quad(row, (TB / 2) * b + q);
+                    mv[2 * q] = LDS(base + (e4[0] & 0xffffu));
+                    ov[2 * q] = LDS(base + (e4[0] >> 16));
+                    sg[2 * q] = e4[1];
+                    mv[2 * q + 1] = LDS(base + (e4[2] & 0xffffu));
+                    ov[2 * q + 1] = LDS(base + (e4[2] >> 16));
+                    sg[2 * q + 1] = e4[3];
                 }
             };
-            auto sum2 = [&](const T (&mv)[16], const T (&ov)[16], const T (&sg)[16]) {
+            auto sum2 = [&](const T (&mv)[TB], const T (&ov)[TB], const u32 (&sg)[TB]) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = FMA(mv[t] * ov[t], sg[t], acc);   // eval.rs:82
+                for (int t = 0; t < TB; ++t) {
+                    const T pr_ = mv[t] * ov[t];
+                    acc = acc + with_hi(pr_, hi_of(pr_) ^ sg[t]);            // eval.rs:82: (l * r) * (+-1), then +=
+                }
             };
+#else
+            T ma[TB], oa[TB], sa[TB], mb[TB], ob[TB], sb[TB];
+            auto load2 = [&](T (&mv)[TB], T (&ov)[TB], T (&sg)[TB], int b) {
+#pragma unroll
+                for (int q = 0; q < TB / 4; ++q) {
+                    const u32x4 e4 = ent2_quad(row, (TB / 4) * b + q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mv[4 * q + j] = LDS(base + (e4[j] & 0xffffu));
+                        ov[4 * q + j] = LDS(base + ((e4[j] >> 16) & 0x7fffu));
+                        u32 hi;
+                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(e4[j]), "s"(0x80000000u), "v"(one_hi));   // +-1.0: the high word
+                        sg[4 * q + j] = pm_one(hi);
+                    }
+                }
+            };
+            auto sum2 = [&](const T (&mv)[TB], const T (&ov)[TB], const T (&sg)[TB]) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t) acc = FMA(mv[t] * ov[t], sg[t], acc);   // eval.rs:82: the product is rounded, +-1 is exact
+            };
+#endif
             if (NB > 0) load2(ma, oa, sa, 0);
             int b = 0;
 #pragma nounroll
@@ -1914,13 +2277,24 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             }
             if (NB & 1) sum2(ma, oa, sa);
 #pragma unroll
-            for (int t = NB * 16; t < W2; ++t) {         // the remainder (compile-time count, no padding terms)
-                const u32 e = word_of(ep[t / 4], t);
-                acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), sgn_of(e, one_hi), acc);
+            for (int t = NB * TB; t < W2; ++t) {         // the remainder (compile-time count, no padding terms)
+#if ENT2_MODE == 2
+                const u32x4 e4 = ent2_quad(row, t / 2);
+                const u32 e = e4[2 * (t & 1)], sgb = e4[2 * (t & 1) + 1];
+                const T pr_ = LDS(base + (e & 0xffffu)) * LDS(base + (e >> 16));
+                acc = acc + with_hi(pr_, hi_of(pr_) ^ sgb);
+#else
+                const u32 e = ent2_quad(row, t / 4)[t & 3];
+                acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), pm_one((e & 0x80000000u) | ONE_HI), acc);
+#endif
             }
             if (it < nitems) out[(item0 + it) * s_out + oo] = acc;
         }
         __syncthreads();   // the rows are rewritten by the next group
+        if (!more) break;
+        g = gn;
+        if (pre_next) commit();
+        else stage_all(gn * IPB, nnext);
     }
 }
 )JIT";
@@ -1928,9 +2302,11 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     c.chain_jit_source = std::move(src);
     const int64_t lay[7] = {off_l1, off_r1, off_neg, off_mid, alias ? -1 : off_r2, stride, neg_is_left ? 1 : 0};
     for (int i = 0; i < 7; ++i) c.cj_layout[i] = int(lay[i]);
+    c.cj_fmt[0] = int(w1s);
+    c.cj_fmt[1] = ent2_mode;
     c.cj_ipb = int(ipb);
     c.cj_threads = int(threads);
-    c.cj_lds = size_t(items_bytes + (ent2_lds ? ent2_bytes : 0) + (ent1_lds ? ent1_bytes : 0));
+    c.cj_lds = size_t(used);
 }
 
 // A list product whose result is read ONLY by another list product (as either operand): both run in ONE k_product_ell_chain
@@ -2022,7 +2398,7 @@ static void chain_list_into_list(Plan& plan) {
             c.pre_width = w.ell_width;
             c.name += " <- " + w.name + " in LDS";
             c.n_entries += w.n_entries;
-            make_chain_jit(plan, c, w, l1, r1, mid, r2, alias, side, covered);
+            make_chain_jit(plan, c, &w, l1, r1, mid, r2, alias, side, covered);
             (side == 1 ? c.a : c.b) = BufRef{BufKind::NODE, -1};
             plan.node_dead[size_t(buf.idx)] = 1;
             w.kind = Step::ZERO;   // marks the first list for removal below
@@ -2033,6 +2409,49 @@ static void chain_list_into_list(Plan& plan) {
     for (Step& t : plan.steps)
         if (!(t.kind == Step::ZERO && t.res.kind == BufKind::NODE && t.res.idx < 0)) kept.push_back(std::move(t));
     plan.steps = std::move(kept);
+}
+
+// A list with FEW LONG rows that stayed a launch of its own -- b * c projected on a low grade: (a + b * c).g(2) at n = 8 is 28 rows of 256
+// terms -- gives k_product_ell (a thread per row) 28 busy threads per workgroup.  The specialised chain kernel's second list is exactly
+// this shape (lane = (row, item), 32 items per workgroup): the list runs on it alone.  When the step before it is the covering copy of
+// an input's grades into the same buffer (a + ...), that copy is folded in as well: the accumulators start from 0.0 + a -- ONE launch.
+// Same order, same roundings; k_product_ell (and the copy) stay in charge when hiprtc is not available.
+static void jit_long_row_lists(Plan& plan) {
+    if (plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_NO_JIT | GAAST_FLAG_DEBUG_JIT_FAILS | GAAST_FLAG_DEBUG_NO_CHAIN)) return;
+    auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
+    auto row_len = [&](BufRef r) -> int64_t {
+        return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)].row_len : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)].row_len
+                                                                                                           : plan.out_layout.row_len;
+    };
+    for (size_t j = 0; j < plan.steps.size(); ++j) {
+        Step& c = plan.steps[j];
+        if (c.kind != Step::PRODUCT_CSR || c.ell_width < 32 || !c.ell_bytes || c.list_chain || c.chain_jit) continue;
+        const int64_t rows = int64_t(c.u32_b.size());
+        if (rows > 64 || c.a.idx < 0 || c.b.idx < 0) continue;
+        const int64_t la = row_len(c.a), lb = row_len(c.b);
+        // the covering copy right before it, into the same buffer?
+        std::vector<uint32_t> init;
+        bool fold = false;
+        if (j > 0 && c.beta == 1) {
+            const Step& ax = plan.steps[j - 1];
+            if (ax.kind == Step::AXPY && ax.beta == 0 && same(ax.res, c.res) && ax.a.kind == BufKind::INPUT && int64_t(ax.u32_a.size()) == rows) {
+                std::vector<int64_t> src_of(size_t(row_len(c.res)), -1);
+                for (uint32_t m : ax.u32_a) src_of[m & 0xffffu] = int64_t(m >> 16);
+                fold = true;
+                for (int64_t r = 0; r < rows && fold; ++r) {
+                    fold = src_of[c.u32_b[size_t(r)]] >= 0;
+                    init.push_back(uint32_t(fold ? src_of[c.u32_b[size_t(r)]] : 0));
+                }
+            }
+        }
+        make_chain_jit(plan, c, nullptr, 0, 0, la, lb, 0, 1, true, fold ? &init : nullptr);
+        if (!c.chain_jit) continue;
+        c.list_jit = 1;
+        if (fold) {
+            c.fold_prev = 1;
+            c.pre_a = plan.steps[j - 1].a;   // the copy's source: the accumulators' starting values
+        }
+    }
 }
 
 void build_plan(const gaast_program_desc& desc, Plan& plan) {
@@ -2108,6 +2527,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
         chain_sparse_into_dense(plan);
         uniform_csr_to_ell(plan);
         chain_list_into_list(plan);
+        jit_long_row_lists(plan);
     }
 }
 

@@ -113,8 +113,11 @@ struct Step {
     void* d_cj_pos1 = nullptr;
     void* d_cj_ent2 = nullptr;
     void* d_cj_out2 = nullptr;
+    int list_jit = 0;                    // the specialised kernel runs a SINGLE list (few long rows): plan.cpp: jit_long_row_lists
+    int fold_prev = 0;                   // ... and, once compiled, also the covering copy_grades_from step right before it (pre_a = its source)
     int cj_ipb = 0, cj_threads = 0;
     size_t cj_lds = 0;
+    int cj_fmt[2] = {0, 0};                     // words per row of list 1's table; list 2's entries: 2 = wide (8 bytes: offsets, then the sign bit), else narrow
     int cj_layout[7] = {0, 0, 0, 0, 0, 0, 0};   // an item in LDS, elements: offsets of l1, r1, the negated image, mid, r2 (-1: aliased); item stride; negated image is of the left operand
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
@@ -132,6 +135,7 @@ struct Step {
     };
     std::vector<FusedInput> fused_inputs;
     int fused_slab = 0, fused_out_base = 0, fused_zero_slot = 0;
+    int jit_items = 0;        // items per workgroup of the specialised kernel when it is not one per thread (the slab-in-LDS form: 64)
     int jit_threads = 256;    // workgroup size of the specialised kernel (64: one wave per workgroup, coalesced row I/O through LDS)
     int fused_jit_only = 0;   // the slab is too big for the LDS interpreter: runs only as the hiprtc-specialised kernel
     std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
@@ -188,7 +192,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan);
 
 // Micro-op encoding shared by the plan builder and k_ast_fused (see kernels.hip.hpp).
 namespace uop {
-enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, LINE_MACS_CNT = 4, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7 };
+enum : uint32_t { LINE_MACS = 0, LINE_MISC = 1, LINE_NOP = 2, LINE_MACS_GEN = 3, LINE_MACS_CNT = 4, ADD = 3, NEG = 4, ZERO = 5, INV = 6, SQRT = 7, COPY = 8 };
 constexpr int MAX_GENERAL_COEFFS = 6;
 constexpr int MAX_INPUTS = 8;
 constexpr int GROUPS = 8;  // waves per workgroup of k_ast_fused (FUSED_GROUPS)

@@ -222,11 +222,11 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             return set_err(GAAST_ERR_UNIMPLEMENTED,
                            "product operands of " + std::to_string(per_item) + " bytes per item do not fit the " +
                                std::to_string(g_max_lds) + "-byte LDS of the list kernels (" + s.name + ")");
-        if (s.list_chain && s.chain_jit == 2) {
-            // the chain specialised through hiprtc (plan.cpp: make_chain_jit): static LDS, persistent workgroups
+        if (s.chain_jit == 2) {
+            // the chain (or single long-row list) specialised through hiprtc (plan.cpp: make_chain_jit): static LDS, persistent workgroups
             s.threads = s.cj_threads;
             s.lds = s.cj_lds;
-            s.hip_kernel = "gaast_chain<" + tn + ">[" + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads]";
+            s.hip_kernel = "gaast_chain<" + tn + ">[" + (s.list_jit ? "one list, " : "") + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads]";
             int per_cu = 0;
             HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, static_cast<hipFunction_t>(s.jit_function), s.threads, 0));
             s.blocks_per_cu = per_cu < 1 ? 1 : per_cu;
@@ -364,14 +364,18 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         }
         if (s.use_mfma6) {
             // k_gp_mfma6<T>: one wave per item, persistent single-wave workgroups, 2 KiB (f32) / 4 KiB (f64) of operand images
-            s.threads = 64;
-            s.items_per_block = 1;
-            s.lds = is_f64 ? 4096 : 2048;
+            s.threads = 64 * GAAST_MFMA6_WAVES;
+            s.items_per_block = GAAST_MFMA6_WAVES;
+            s.lds = size_t(is_f64 ? 4096 : 2048) * GAAST_MFMA6_WAVES;
             using KernD = void (*)(DenseArgs<T>);
-            const KernD k6 = s.scaled ? &k_gp_mfma6<T, true> : &k_gp_mfma6<T, false>;
+            // [0]: any operands (partial grade sets, projected or accumulated results); [1]: full operands, every blade produced, nothing
+            // accumulated -- straight-line item loop with counted waits
+            const KernD k6 = s.scaled ? &k_gp_mfma6<T, true, false> : &k_gp_mfma6<T, false, false>;
+            const KernD k6f = s.scaled ? &k_gp_mfma6<T, true, true> : &k_gp_mfma6<T, false, true>;
             s.kern[0] = reinterpret_cast<const void*>(k6);
-            s.hip_kernel = "k_gp_mfma6<" + tn + (s.scaled ? ",true>" : ",false>");
-            return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
+            s.kern[1] = reinterpret_cast<const void*>(k6f);
+            s.hip_kernel = "k_gp_mfma6<" + tn + (s.scaled ? ",true,0|1>" : ",false,0|1>");
+            return resident_blocks(s.kern[1], s.threads, s.lds, &s.blocks_per_cu);
         }
         if (s.use_mfma7) {
             // k_gp_mfma7<T>: one wave per item, single-wave workgroups
@@ -430,7 +434,7 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         const int nm = int(s.u32_a.size());
         hipLaunchKernelGGL(k_axpy_map<T>, dim3(grid_for(batch * nm, 256)), dim3(256), 0, g_stream,
                            static_cast<T*>(res.ptr), res.stride, static_cast<const T*>(a.ptr), a.stride,
-                           static_cast<const uint32_t*>(s.d_a), nm, batch);
+                           static_cast<const uint32_t*>(s.d_a), nm, batch, s.beta);
         break;
     }
     case Step::FLIP: {
@@ -467,14 +471,17 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         break;
     }
     case Step::PRODUCT_CSR: {
-        if (s.list_chain && s.chain_jit == 2) {
+        if (s.chain_jit == 2) {
             const bool mid_left = s.list_chain == 1;
-            const Bound& other = s.chain_alias ? pre_a : (mid_left ? b : a);
-            const void *l1 = pre_a.ptr, *r1 = pre_b.ptr, *r2 = other.ptr;
-            long long s_l1 = pre_a.stride, s_r1 = pre_b.stride, s_r2 = other.stride, s_out = res.stride, nb = batch;
+            const Bound& other = s.list_jit ? b : s.chain_alias ? pre_a : (mid_left ? b : a);
+            // a single list: its left operand is staged as the "mid" row (pointer l1), its right one is list 2's own operand (r2)
+            const void *l1 = s.list_jit ? a.ptr : pre_a.ptr, *r1 = s.list_jit ? nullptr : pre_b.ptr, *r2 = other.ptr;
+            long long s_l1 = s.list_jit ? a.stride : pre_a.stride, s_r1 = s.list_jit ? 0 : pre_b.stride, s_r2 = other.stride, s_out = res.stride, nb = batch;
             void* optr = res.ptr;
             const void *e1 = s.d_cj_ent1, *p1 = s.d_cj_pos1, *e2 = s.d_cj_ent2, *o2 = s.d_cj_out2;
-            void* args[] = {&l1, &s_l1, &r1, &s_r1, &r2, &s_r2, &optr, &s_out, &e1, &p1, &e2, &o2, &nb};
+            const void* init = (s.list_jit && s.fold_prev) ? pre_a.ptr : nullptr;
+            long long s_init = (s.list_jit && s.fold_prev) ? pre_a.stride : 0;
+            void* args[] = {&l1, &s_l1, &r1, &s_r1, &r2, &s_r2, &optr, &s_out, &e1, &p1, &e2, &o2, &nb, &init, &s_init};
             int64_t blocks = (batch + s.cj_ipb - 1) / s.cj_ipb;
             blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * s.blocks_per_cu);
             // (the argument block is copied into the dispatch packet at call time, like run_jit's)
@@ -673,7 +680,8 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         p.out_scale = s.scaled ? static_cast<const T*>(s.d_coeff_c) : nullptr;
         // register-prefetch staging: full, contiguous, aligned operand rows; a chained step computes its left operand from a list
         // (then only the right row is prefetched)
-        const bool prefetch = s.use_mfma7 ? (s.kern[1] && p.right_full && !s.scaled && (s.chained || p.left_full))   // one component per lane and load: no alignment needed
+        const bool prefetch = s.use_mfma6 ? (p.left_full && p.right_full && s.out_full && !s.beta)   // k_gp_mfma6's straight-line instantiation
+                              : s.use_mfma7 ? (s.kern[1] && p.right_full && !s.scaled && (s.chained || p.left_full))   // one component per lane and load: no alignment needed
                                           : (s.use_mfma16 && s.kern[1] && p.right_contig && p.right_full && !s.scaled &&
                                              (s.chained ? true : (p.left_contig && p.left_full)));
         const bool whole_rows = prefetch && s.kern[2] && s.out_full && !s.beta;   // k_gp_mfma16x4: straight-line result stores
@@ -749,7 +757,8 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     void* dom = s.d_domain;
     if (plan.has_explog) args.push_back(&dom);
     const unsigned threads = unsigned(s.jit_threads);
-    const unsigned blocks = unsigned((batch + threads - 1) / threads);
+    const unsigned per_block = unsigned(s.jit_items > 0 ? s.jit_items : s.jit_threads);   // (the slab-in-LDS form: 64 items per 512 threads)
+    const unsigned blocks = unsigned((batch + per_block - 1) / per_block);
     // (the argument block -- args, ptrs, strides and the locals they point at -- only has to live until this call returns:
     //  hipModuleLaunchKernel copies the kernel arguments into the dispatch packet's kernarg segment at call time)
     HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,
@@ -898,7 +907,7 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             std::string log;
             const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, s.jit_source, "gaast_jit", &log);
             if (ok)
-                s.name = "ast_jit" + s.name.substr(s.name.find('['));
+                s.name = "ast_jit" + s.name.substr(s.name.find('[')) + (s.jit_items ? " slab in LDS" : "");
             else if (!log.empty())
                 g_err = "hiprtc: " + log;  // informational: the interpreter kernel (or an unfused plan) runs instead
             std::string().swap(s.jit_source);
@@ -917,14 +926,27 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
         if (!prog->plan.unsupported.empty()) return set_err(GAAST_ERR_UNIMPLEMENTED, prog->plan.unsupported);
     }
     // list chains specialised per program; on any failure the generic k_product_ell_chain stays in charge
-    for (Step& s : prog->plan.steps) {
-        if (s.chain_jit != 1) continue;
-        if (desc->flags & GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE) prog->plan.jit_source_kept += s.chain_jit_source;
-        std::string log;
-        const bool ok = jit_compile(s, s.chain_jit_source, "gaast_chain", &log);
-        if (!ok && !log.empty()) g_err = "hiprtc: " + log;
-        s.chain_jit = ok ? 2 : 0;
-        std::string().swap(s.chain_jit_source);
+    {
+        std::vector<char> drop(prog->plan.steps.size(), 0);
+        for (size_t i = 0; i < prog->plan.steps.size(); ++i) {
+            Step& s = prog->plan.steps[i];
+            if (s.chain_jit != 1) continue;
+            if (desc->flags & GAAST_FLAG_DEBUG_KEEP_JIT_SOURCE) prog->plan.jit_source_kept += s.chain_jit_source;
+            std::string log;
+            const bool ok = jit_compile(s, s.chain_jit_source, "gaast_chain", &log);
+            if (!ok && !log.empty()) g_err = "hiprtc: " + log;
+            s.chain_jit = ok ? 2 : 0;
+            std::string().swap(s.chain_jit_source);
+            if (ok && s.fold_prev && i > 0) {   // the copy_grades_from step before a single list is evaluated by the specialised kernel
+                drop[i - 1] = 1;
+                s.name += " <- " + prog->plan.steps[i - 1].name;
+            }
+            if (!ok) s.list_jit = s.fold_prev = 0;
+        }
+        std::vector<Step> kept;
+        for (size_t i = 0; i < prog->plan.steps.size(); ++i)
+            if (!drop[i]) kept.push_back(std::move(prog->plan.steps[i]));
+        prog->plan.steps = std::move(kept);
     }
     Plan& plan = prog->plan;
     auto layout_of = [&](BufRef r) -> Layout {
@@ -976,9 +998,9 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             if (int st = upload_t(s.pre_coeff, &s.d_pre_coeff)) return st;
             if (int st = upload_t(s.pre_row_scale, &s.d_pre_row_scale)) return st;
         }
-        if (s.list_chain) {
-            if (s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
-            if (s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
+        if (s.list_chain || s.list_jit) {
+            if (s.pre_a.idx >= 0 && s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
+            if (s.list_chain && s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
             if (s.chain_jit == 2) {
                 if (int st = upload_vec(s.cj_ent1, &s.d_cj_ent1)) return st;
                 if (int st = upload_vec(s.cj_pos1, &s.d_cj_pos1)) return st;
@@ -1297,6 +1319,9 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
             Layout unused;
             pa = resolve(s.pre_a, &unused);
             pb = resolve(s.pre_b, &unused);
+        } else if (s.list_jit && s.fold_prev) {
+            Layout unused;
+            pa = resolve(s.pre_a, &unused);   // the folded copy's source
         }
         const int st = plan.dtype == GAAST_F32 ? run_step<float>(s, res, a, b, la, lb, count, step_n, pa, pb)
                                                : run_step<double>(s, res, a, b, la, lb, count, step_n, pa, pb);

@@ -142,7 +142,7 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
     // the kernel's algebra: the program's, or Cl(n - 1) for parity-pure operands (st->dense_n)
     const int n2 = st->dense_n ? st->dense_n : n;
     const uint32_t N = 1u << n2, NROW = 1u << n;
-    const int L = st->use_mfma ? 5 : st->use_mfma7 ? 3 : 4;
+    const int L = st->use_mfma ? 5 : st->use_mfma7 ? 3 : st->use_mfma6 ? 0 : 4;   // (k_gp_mfma6: no lo vectors, the image position is the blade)
     // operands: a fixed pseudo-random row each (exact small integers: every sum below is exact)
     std::vector<double> lrow(NROW), rrow(NROW);
     uint64_t x = 88172645463325252ULL;
@@ -167,7 +167,8 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
         size_t idx = 0;
         for (uint32_t w : map) {
             const uint32_t off = w & 0xffffu, pos = (w >> 16) & 0x7fffu;
-            const uint32_t blade = st->use_mfma7 ? (right ? inv_b[pos] : inv_a7[pos])
+            const uint32_t blade = st->use_mfma6 ? pos
+                                   : st->use_mfma7 ? (right ? inv_b[pos] : inv_a7[pos])
                                    : (st->use_mfma || st->use_mfma16) ? (right ? inv_b[pos] : pos) : inv_vec[pos];
             uint32_t neg = w >> 31;
             // the image-pair kernels keep the b_hi part of (-1)^(|a_hi| |b_lo|) in the B image (the kernel supplies the
@@ -258,8 +259,8 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
     const int esz = dtype == GAAST_F32 ? 4 : 8;
     const int l1 = s.pre_left_len, r1 = s.pre_right_len, mid = s.chain_mid_len;
     const int rows1 = int(s.pre_row_map.size()), w1 = s.pre_width, rows2 = int(s.u32_b.size()), w2 = s.ell_width;
-    const int w1p = (w1 + 3) & ~3, w2p = (w2 + 3) & ~3;
-    CHECK(int(s.cj_ent1.size()) == rows1 * w1p && int(s.cj_ent2.size()) == rows2 * w2p && s.chain_alias == 1 && s.list_chain == 1);
+    const int w1p = s.cj_fmt[0], w2p = (w2 + 3) & ~3, wide = s.cj_fmt[1] == 2 ? 2 : 1;
+    CHECK(int(s.cj_ent1.size()) == rows1 * w1p && int(s.cj_ent2.size()) == rows2 * w2p * wide && s.chain_alias == 1 && s.list_chain == 1);
     std::vector<double> L(static_cast<size_t>(l1), 0.0), X(static_cast<size_t>(r1), 0.0);
     unsigned long long seed = 88172645463325252ull + unsigned(n);
     auto rnd = [&]() {
@@ -310,9 +311,11 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
     for (int row = 0; row < rows2; ++row) {
         double acc = 0.0;
         for (int t = 0; t < w2; ++t) {
-            const uint32_t w = s.cj_ent2[size_t(row) * w2p + t];
-            const double p = at(w & 0xffffu) * at((w >> 16) & 0x7fffu);
-            acc = acc + ((w & 0x80000000u) ? -p : p);
+            const uint32_t w = s.cj_ent2[(size_t(row) * w2p + t) * wide];
+            const uint32_t sign = wide == 2 ? s.cj_ent2[(size_t(row) * w2p + t) * 2 + 1] : (w & 0x80000000u);
+            CHECK(sign == 0u || sign == 0x80000000u);
+            const double p = at(w & 0xffffu) * at(wide == 2 ? (w >> 16) : ((w >> 16) & 0x7fffu));
+            acc = acc + (sign ? -p : p);
         }
         same = same && std::memcmp(&acc, &out_a[size_t(row)], sizeof acc) == 0 && s.cj_out2[size_t(row)] == s.u32_b[size_t(row)];
     }
@@ -321,8 +324,87 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
     gaast_spec_free(spec);
 }
 
+// ... and a SINGLE list with few long rows on the same kernel (plan.cpp: jit_long_row_lists): d = (a + b * c).g(2), the covering copy of
+// a's grade 2 folded into the list's accumulators.  Generic ELL words against the specialised tables, bit for bit.
+static void single_list_tables_agree(int n, int dtype, const char* dump_dir) {
+    std::vector<double> metric(size_t(n), 1.0);
+    gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n), c = gaast_expr_input(2, full_mask(n), n);
+    gaast_expr_t e = gaast_expr_g(gaast_expr_add(a, gaast_expr_product(b, c, GAAST_PROD_GEOMETRIC)), 2);
+    gaast_spec_t spec = gaast_expr_specialize(e, n, metric.data(), uint64_t(1) << 22);
+    CHECK(spec != nullptr);
+    if (!spec) return;
+    gaast_program_desc desc;
+    CHECK(gaast_spec_program_desc(spec, dtype, 0, &desc) == 0);
+    gaast::Plan plan;
+    gaast::build_plan(desc, plan);
+    CHECK(plan.steps.size() == 2 && plan.steps[0].kind == gaast::Step::AXPY && plan.steps[0].beta == 0 && plan.steps[1].list_jit == 1 &&
+          plan.steps[1].fold_prev == 1 && plan.steps[1].chain_jit == 1);
+    if (plan.steps.size() != 2 || !plan.steps[1].list_jit) {
+        for (const gaast::Step& st : plan.steps) std::printf("    step %s\n", st.name.c_str());
+        gaast_spec_free(spec);
+        return;
+    }
+    const gaast::Step& ax = plan.steps[0];
+    const gaast::Step& s = plan.steps[1];
+    if (dump_dir) {
+        char path[512];
+        std::snprintf(path, sizeof path, "%s/list_n%d_%s.hip", dump_dir, n, dtype == GAAST_F32 ? "f32" : "f64");
+        if (FILE* f = std::fopen(path, "w")) {
+            std::fputs(s.chain_jit_source.c_str(), f);
+            std::fclose(f);
+        }
+    }
+    const int esz = dtype == GAAST_F32 ? 4 : 8;
+    const int N = 1 << n, rows = int(s.u32_b.size()), w2 = s.ell_width, w2p = (w2 + 3) & ~3, wide = s.cj_fmt[1] == 2 ? 2 : 1;
+    std::vector<double> A(static_cast<size_t>(N), 0.0), B(static_cast<size_t>(N), 0.0), Cc(static_cast<size_t>(N), 0.0);
+    unsigned long long seed = 1234567ull + unsigned(n);
+    auto rnd = [&]() {
+        seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+        return double(int64_t(seed >> 11)) / double(1ull << 52) - 1.0;
+    };
+    for (double& v : A) v = rnd();
+    for (double& v : B) v = rnd();
+    for (double& v : Cc) v = rnd();
+    // (a) the two-launch plan: copy, then the generic ELL words accumulate onto it
+    std::vector<double> out_a(size_t(rows), 0.0);
+    for (uint32_t m : ax.u32_a) out_a[m & 0xffffu] = 0.0 + A[m >> 16];
+    for (int row = 0; row < rows; ++row) {
+        double acc = out_a[s.u32_b[size_t(row)]];
+        for (int t = 0; t < w2; ++t) {
+            const uint32_t w = s.u32_c[size_t(t) * rows + row];
+            const double p = B[(w & 0x7fffu) / esz] * Cc[((w >> 16) & 0x7fffu) / esz];
+            acc = acc + ((w & 0x80000000u) ? -p : p);
+        }
+        out_a[s.u32_b[size_t(row)]] = acc;
+    }
+    // (b) the specialised tables over the item image: left operand at cj_layout[3] ("mid"), right one at cj_layout[4]
+    const int* lay = s.cj_layout;
+    std::vector<double> img(size_t(lay[5]), 0.0);
+    for (int c2 = 0; c2 < N; ++c2) img[size_t(lay[3] + c2)] = B[size_t(c2)];
+    for (int c2 = 0; c2 < N; ++c2) img[size_t(lay[4] + c2)] = Cc[size_t(c2)];
+    bool same = int(s.cj_pos1.size()) == rows;
+    for (int row = 0; row < rows && same; ++row) {
+        double acc = 0.0 + A[s.cj_pos1[size_t(row)]];
+        for (int t = 0; t < w2; ++t) {
+            const uint32_t w = s.cj_ent2[(size_t(row) * w2p + t) * wide];
+            const uint32_t sign = wide == 2 ? s.cj_ent2[(size_t(row) * w2p + t) * 2 + 1] : (w & 0x80000000u);
+            const uint32_t mo = w & 0xffffu, oo = wide == 2 ? (w >> 16) : ((w >> 16) & 0x7fffu);
+            CHECK(mo % esz == 0 && oo % esz == 0 && mo / esz < uint32_t(lay[5]) && oo / esz < uint32_t(lay[5]));
+            const double p = img[mo / esz] * img[oo / esz];
+            acc = acc + (sign ? -p : p);
+        }
+        same = std::memcmp(&acc, &out_a[s.cj_out2[size_t(row)]], sizeof acc) == 0;
+    }
+    if (!same) std::printf("single list n=%d: the specialised tables compute another result\n", n);
+    CHECK(same);
+    gaast_spec_free(spec);
+}
+
 int main(int argc, char** argv) {
     const char* dump_dir = argc > 1 ? argv[1] : nullptr;
+    single_list_tables_agree(8, GAAST_F64, dump_dir);
+    single_list_tables_agree(8, GAAST_F32, dump_dir);
+    single_list_tables_agree(9, GAAST_F64, dump_dir);
     {
         const double euclid16[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         const double mixed9[9] = {1, 1, 1, 1, 1, 1, -1, -1, -1};
@@ -416,10 +498,15 @@ int main(int argc, char** argv) {
     }
     {   // dense tables under a basis permutation == the reference's list, for every kernel's table format
         const double pga6[6] = {0, 1, 1, 1, 1, -1}, anti6[6] = {-1, 1, -1, -1, -1, 1}, sta6[6] = {-1, 1, 1, 1, 0, 1};
-        dense_tables_agree_with_the_list(6, euclid, GAAST_F64, 0, "dense tables n=6 euclid", "product_dense[gp n=6]");
-        dense_tables_agree_with_the_list(6, pga6, GAAST_F64, 0, "dense tables n=6 null vector first", "permuted basis");
-        dense_tables_agree_with_the_list(6, anti6, GAAST_F64, 0, "dense tables n=6 four negative lo vectors", "permuted basis");
-        dense_tables_agree_with_the_list(6, sta6, GAAST_F32, 0, "dense tables n=6 time first", "permuted basis");
+        dense_tables_agree_with_the_list(6, euclid, GAAST_F64, GAAST_FLAG_NO_MFMA, "dense tables n=6 euclid", "product_dense[gp n=6]");
+        dense_tables_agree_with_the_list(6, pga6, GAAST_F64, GAAST_FLAG_NO_MFMA, "dense tables n=6 null vector first", "permuted basis");
+        dense_tables_agree_with_the_list(6, anti6, GAAST_F64, GAAST_FLAG_NO_MFMA, "dense tables n=6 four negative lo vectors", "permuted basis");
+        dense_tables_agree_with_the_list(6, sta6, GAAST_F32, GAAST_FLAG_NO_MFMA, "dense tables n=6 time first", "permuted basis");
+        // k_gp_mfma6 (round 4): the basis as it stands, the image position is the blade, all six signature bits in neg_hi / zero_hi
+        dense_tables_agree_with_the_list(6, euclid, GAAST_F64, 0, "mfma6 tables n=6 euclid", "product_dense_mfma[gp n=6]");
+        dense_tables_agree_with_the_list(6, pga6, GAAST_F64, 0, "mfma6 tables n=6 null vector first", "product_dense_mfma[gp n=6]");
+        dense_tables_agree_with_the_list(6, anti6, GAAST_F32, 0, "mfma6 tables n=6 four negative vectors", "product_dense_mfma[gp n=6]");
+        dense_tables_agree_with_the_list(6, sta6, GAAST_F32, 0, "mfma6 tables n=6 time first, a null vector", "product_dense_mfma[gp n=6]");
         const double pga8[8] = {0, 1, 1, 1, 1, 1, 1, 1}, neg8[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, mix8[8] = {1, 0, -1, 1, 0, -1, 1, -1};
         dense_tables_agree_with_the_list(8, pga8, GAAST_F32, 0, "mfma16 tables n=8 null vector first", "product_dense_mfma");
         dense_tables_agree_with_the_list(8, neg8, GAAST_F32, 0, "mfma16 tables Cl(0,8)", "product_dense_mfma[gp n=8]");

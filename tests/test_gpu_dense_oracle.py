@@ -555,7 +555,7 @@ def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtyp
         got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
         two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
         assert np.array_equal(got, two), (k, spec.launches(), spec2.launches())
-        if not any("ast_fused" in l for l in spec.launches()):     # (f32 slabs of the third program fit the LDS interpreter: one launch anyway)
+        if not any("ast_fused" in l or "ast_jit" in l for l in spec.launches()):     # (f32 slabs of the third program fit a fused launch: one launch anyway)
             assert any("gaast_chain<" in l for l in spec.launches()), (k, spec.launches())
             gen, _, spec3 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT)    # the generic kernel
             assert np.array_equal(gen, two) and any("k_product_ell_chain<" in l or "ast_fused" in l for l in spec3.launches()), (k, spec3.launches())
@@ -563,3 +563,61 @@ def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtyp
         rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
         want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
         assert mask == wmask and np.array_equal(got.astype(np.float64), want), k
+
+
+@pytest.mark.parametrize("metric", [[1.0] * 6,                                # R^6
+                                    [1.0, 1.0, 1.0, 1.0, -1.0, -1.0],         # R^{4,2} (conformal space-time style)
+                                    [1.0, -1.0, 1.0, -1.0, 1.0, -1.0],        # R^{3,3}: -1 in every bit group (lo, hi, top)
+                                    [0.0, 1.0, 1.0, 1.0, -1.0, 0.0],          # null vectors in the lo AND the top group, a -1 in the top group
+                                    [1.0, 0.0, -1.0, 0.0, 1.0, 1.0],          # null vectors in the lo and the hi group
+                                    [-1.0] * 6,                               # Cl(0,6)
+                                    [2.0, 0.5, -4.0, 1.0, -0.25, 3.0]])       # general diagonal metric: the rescaled basis
+def test_n6_runs_on_the_matrix_cores_in_any_diagonal_metric(metric):
+    """k_gp_mfma6<T> (round 4): n = 6 -- where PGA3D / CGA-adjacent algebras live -- on FOUR 16x16x4 instructions per item, both
+    value types, any diagonal metric in the basis as it stands (signs and null vectors are slots of the operand images and bits
+    of the accumulators; tools/proto/mfma6_tile.py is the CPU emulation of the decomposition).  Full operands, a ragged batch
+    beyond the four items a wave keeps in flight, against the oracle within 4 eps sum |terms| (8 for the rescaled basis)."""
+    general = any(m not in (1.0, -1.0, 0.0) for m in metric)
+    sc = "true" if general else "false"
+    variants = [(ga.F32, 0, "product_dense_mfma[", f"k_gp_mfma6<float,{sc},"), (ga.F64, 0, "product_dense_mfma[", f"k_gp_mfma6<double,{sc},")]
+    if metric == [1.0] * 6:     # the vector kernel it replaces stays behind GAAST_FLAG_NO_MFMA
+        variants += [(ga.F32, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<float,"), (ga.F64, ga.FLAG_NO_MFMA, "product_dense[", "k_gp_dense<double,")]
+    # (a general metric's list has general coefficients: the reference's summation order stays available on k_product_csr)
+    _check(6, metric, None, variants, batch=1003, seed=600 + int(sum(metric)), eps_factor=8 if general else 4, exact_order_too=general)
+
+
+@pytest.mark.parametrize("dtype", [ga.F32, ga.F64])
+def test_n6_partial_operands_projected_result_accumulation_and_shared_rows(dtype):
+    """k_gp_mfma6 beyond the plain product: operands that hold only some grades (components nobody loads stay zero in the
+    images), a grade-projected result (stores skipped), a sum of two products into one buffer (beta = 1) and one operand row
+    shared by every item (stride 0)."""
+    n, batch = 6, 77
+    rng = np.random.default_rng(66)
+    npdt, eps = (np.float32, 2.0 ** -23) if dtype == ga.F32 else (np.float64, 2.0 ** -52)
+    metric = [1.0, 1.0, -1.0, 1.0, 0.0, 1.0]
+    lg, rg, og = [0, 1, 2, 3, 4, 6], [1, 2, 3, 4, 5], [0, 2, 3, 5, 6]
+    build = lambda B: (B.input(0, lg, n) * B.input(1, rg, n)).gselect(og) + (B.input(2, full_grades(n), n) * B.input(1, rg, n)).gselect(og)
+    rows = {0: rows_of(n, lg, batch, rng, np.float32), 1: rows_of(n, rg, 1, rng, np.float32), 2: rows_of(n, full_grades(n), batch, rng, np.float32)}
+    rows64 = {s: r.astype(np.float64) for s, r in rows.items()}
+    want, wmask = oracle_eval_batch(build, metric, rows64, batch)
+    got, mask, spec = hip_eval_batch(build, metric, {s: r.astype(npdt) for s, r in rows.items()}, batch, dtype=dtype)
+    assert mask == wmask
+    kern = "k_gp_mfma6<float," if dtype == ga.F32 else "k_gp_mfma6<double,"
+    assert sum(kern in l for l in spec.launches()) == 2, spec.launches()
+    ogl = [k for k in range(n + 1) if (wmask >> k) & 1]
+    for i in range(batch):
+        S = abs_terms_bound(n, row_to_bits(n, lg, rows64[0][i]), row_to_bits(n, rg, rows64[1][0])) + \
+            abs_terms_bound(n, row_to_bits(n, full_grades(n), rows64[2][i]), row_to_bits(n, rg, rows64[1][0]))
+        bound = 4 * eps * bits_to_row(n, ogl, S) + 1e-300
+        err = np.abs(got[i].astype(np.float64) - want[i])
+        assert np.all(err <= bound), (i, float((err / bound).max()))
+
+
+def test_n7_parity_pure_products_run_in_cl6_on_the_matrix_cores():
+    """even x even and odd x even at n = 7 are ONE product in the even subalgebra Cl(6) (plan.cpp rewrite 7): k_gp_mfma6"""
+    n = 7
+    for lpar, rpar in (("even", "even"), ("odd", "even")):
+        grades = {"even": EVEN(n), "odd": ODD(n)}
+        _check(n, [1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0], grades[lpar],
+               [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma6<float,false,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma6<double,false,")],
+               batch=33, seed=770, right_grades=grades[rpar], label_has=f"{lpar} x {rpar} in Cl(6)")
