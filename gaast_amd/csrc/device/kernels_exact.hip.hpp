@@ -194,6 +194,149 @@ __global__ __launch_bounds__(256) void k_product_csr(CsrArgs<T> p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_reduce_scale: out = x (*) f(<l, r>) -- a product whose result is ONE scalar component (a single row of n1 terms: norm_sq =
+// (a.rev() * a).g(0)), an optional ScalarUnaryOp on it (eval.rs:103-110), and a product of n2 one-term rows that multiplies another
+// row by that scalar: the versor inverse a.rev() * a.norm_sq().sinv() (expr.rs:363-371) and normalisations, at the dimensions where
+// the rows no longer fit a fused slab (n >= 9: 2 x 16 KiB per item at n = 12).  As three launches the single long row occupied one
+// thread per workgroup and the row travelled twice.  Here: ONE launch, sixteen items per wave, persistent:
+//   * the reduction keeps the reference's order and roundings (eval.rs:82: (l * r) * coeff, then +=, term after term): a QUAD of
+//     lanes per item fetches and multiplies four consecutive terms, the chain of additions takes them in lane order -- the loads
+//     of the next round in flight under it;
+//   * 1 / s or sqrt(s), correctly rounded, then 0.0 + s when the scalar is re-read as a product operand (eval.rs:27-31);
+//   * the scaling re-reads its row (from L2 / the Infinity Cache: this wave has just streamed it) and stores 0.0 + (x * s) * coeff.
+// Bit-identical to the three-launch plan and to the oracle.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct ReduceScaleArgs {
+    const T* l1;
+    const T* r1;
+    const T* x;
+    T* out;
+    int64_t l1_stride, r1_stride, x_stride, out_stride;
+    const uint32_t* ent1;   // n1 terms: left offset | right offset << 16 (elements)
+    const T* coeff1;        // n1 coefficients
+    const uint32_t* ent2;   // n2 rows: x offset | out offset << 16
+    const T* coeff2;        // n2 coefficients
+    int n1, n2;
+    int canon_l1, canon_r1, canon_x, canon_s;
+    int s_is_left;          // the scalar is the LEFT operand of the scaling product (values are the same either way)
+    int op;                 // 0 none, 1 inversion, 2 square root
+    int64_t batch;
+};
+
+__device__ __forceinline__ float lane_value(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ double lane_value(double v, int j) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+// the value lane J of this lane's QUAD holds (DPP quad_perm broadcast: no LDS, no scalar round trip)
+template <int J>
+__device__ __forceinline__ float quad_value(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), J * 0x55, 0xf, 0xf, true));
+}
+template <int J>
+__device__ __forceinline__ double quad_value(double v) {
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), J * 0x55, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(v), J * 0x55, 0xf, 0xf, true));
+}
+
+// A QUAD per item in the reduction (16 items per wave): the four lanes of a quad fetch and multiply four consecutive terms of
+// their item, and the chain of additions takes them in lane order through DPP quad broadcasts -- three vector instructions per
+// four-lane step serve SIXTEEN items (one wave per item spent them on one: 6,000 cycles per item and CU at n = 12; wave-wide
+// LDS re-reads of parked products: 8,000).  The scaling then walks the wave's sixteen items with all 64 lanes (coalesced rows).
+template <typename T>
+__global__ __launch_bounds__(256) void k_reduce_scale(ReduceScaleArgs<T> p) {
+    constexpr int CHUNKS = 8;                                  // steps of 4 terms per item and round (their loads in flight one round ahead)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 2, ql = lane & 3;                    // this lane's item of the wave's sixteen, its place in the quad
+    const int64_t n_waves = int64_t(gridDim.x) * 4;
+    const T zero = T(0);
+    const int n_steps = (p.n1 + 3) / 4, n_rounds = (n_steps + CHUNKS - 1) / CHUNKS;
+    const int64_t n_groups = (p.batch + 15) / 16;
+    for (int64_t g = int64_t(blockIdx.x) * 4 + wv; g < n_groups; g += n_waves) {
+        const int64_t item = g * 16 + q;
+        const bool live_item = item < p.batch;
+        const int64_t it = live_item ? item : p.batch - 1;     // (lanes beyond the batch re-read the last item; nothing of theirs is stored)
+        const T* l = p.l1 + it * p.l1_stride;
+        const T* r = p.r1 + it * p.r1_stride;
+        // software pipeline over rounds of CHUNKS steps: a term's operand addresses come from its table word, so the words are
+        // fetched two rounds ahead and the operands one round ahead
+        uint32_t e_cur[CHUNKS], e_nxt[CHUNKS];
+        T lv[CHUNKS], rv[CHUNKS], cf[CHUNKS];
+        auto fetch_words = [&](int round, uint32_t (&e)[CHUNKS]) {
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {
+                const int t = (round * CHUNKS + k) * 4 + ql;
+                e[k] = t < p.n1 ? p.ent1[t] : 0u;
+            }
+        };
+        auto fetch_operands = [&](int round, const uint32_t (&e)[CHUNKS]) {
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {
+                const int t = (round * CHUNKS + k) * 4 + ql;
+                const bool live = t < p.n1;
+                lv[k] = live ? l[e[k] & 0xffffu] : zero;
+                rv[k] = live ? r[e[k] >> 16] : zero;
+                cf[k] = live ? p.coeff1[t] : zero;
+            }
+        };
+        fetch_words(0, e_cur);
+        fetch_words(1, e_nxt);
+        fetch_operands(0, e_cur);
+        T acc = zero;                                         // the fresh cache buffer of eval.rs:21-33
+        for (int round = 0; round < n_rounds; ++round) {
+            T prod[CHUNKS];
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {                // this round's products, rounded as eval.rs:82
+                T a = lv[k], b = rv[k];
+                if (p.canon_l1) a = zero + a;
+                if (p.canon_r1) b = zero + b;
+                prod[k] = (a * b) * cf[k];
+            }
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) e_cur[k] = e_nxt[k];
+            if (round + 1 < n_rounds) fetch_operands(round + 1, e_cur);   // in flight under the chain of additions
+            if (round + 2 < n_rounds) fetch_words(round + 2, e_nxt);
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {                // the chain, term after term (no padding terms: acc + 0.0 is not a no-op for -0.0)
+                const int left = p.n1 - (round * CHUNKS + k) * 4;
+                if (left > 0) acc = acc + quad_value<0>(prod[k]);
+                if (left > 1) acc = acc + quad_value<1>(prod[k]);
+                if (left > 2) acc = acc + quad_value<2>(prod[k]);
+                if (left > 3) acc = acc + quad_value<3>(prod[k]);
+            }
+        }
+        T s = acc;
+        if (p.op == 1) s = T(1) / s;
+        else if (p.op == 2) s = sizeof(T) == 8 ? T(__builtin_sqrt(double(s))) : T(__builtin_sqrtf(float(s)));
+        if (p.canon_s) s = zero + s;
+        // ---- the scaling: all 64 lanes on 64 consecutive rows; a row's table word and coefficient are fetched ONCE and serve the
+        // wave's sixteen items, whose operand loads are all in flight together (item after item, each iteration waiting for its
+        // word and then for its operand, this phase alone took 6,000 cycles per item and CU) ----
+        T sk[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sk[k] = lane_value(s, 4 * k);
+        const int64_t item0 = g * 16;
+        const int n_items = int(p.batch - item0 < 16 ? p.batch - item0 : 16);
+        for (int i0 = 0; i0 < p.n2; i0 += 64) {
+            const int i = i0 + lane;
+            const bool live = i < p.n2;
+            const uint32_t e = live ? p.ent2[i] : 0u;
+            const T c2 = live ? p.coeff2[i] : zero;
+            T xv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xv[k] = (live && k < n_items) ? p.x[(item0 + k) * p.x_stride + (e & 0xffffu)] : zero;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                T v = xv[k];
+                if (p.canon_x) v = zero + v;
+                const T pr = p.s_is_left ? sk[k] * v : v * sk[k];
+                if (live && k < n_items) p.out[(item0 + k) * p.out_stride + (e >> 16)] = zero + pr * c2;   // the fresh result buffer: 0.0 + (l * r) * coeff
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_product_ell: the exact product for lists whose rows (result components) all have the same
 // number of entries and whose coefficients are +-1 -- every dense product of a non-degenerate
 // algebra.  Same terms in the same (reference) order with the same three roundings per term as

@@ -1578,16 +1578,55 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
         src += "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n";
         src += "  const long long item0 = blockIdx.x * 64LL;\n";
         src += "  const int nitems = int(batch - item0 < 64 ? batch - item0 : 64);\n";
-        // inputs: element e = item * len + c of the flattened range, consecutive threads read consecutive elements (coalesced when the
-        // rows are contiguous); rows beyond the batch are zero
+        // inputs: element e = item * len + c of the flattened range.  Contiguous, 16-byte aligned rows of a full group of 64 items are
+        // moved as 16-byte pieces, ALL of them in flight before the first is written to LDS (a group is 64 KiB at slab 259: the
+        // HBM latency is paid once); anything else -- shared rows, strided wrapped memory, the last partial group -- takes a plain loop
+        const int epc = int(16 / elem);
+        src += std::string("  typedef T VT __attribute__((ext_vector_type(") + std::to_string(epc) + ")));\n";
+        std::string fast_cond = "nitems == 64";
+        int total_chunks_per_thread = 0;
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
+            const std::string I = std::to_string(i);
+            fast_cond += " && s" + I + " == " + std::to_string(len) + " && (((unsigned long long)in" + I + ") & 15ull) == 0";
+            if ((64 * len) % epc) fast_cond += " && false";
+            total_chunks_per_thread += (64 * len / epc + 511) / 512;
+        }
+        if (total_chunks_per_thread > 24) fast_cond = "false";
+        src += "  if (" + fast_cond + ") {\n";
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
+            const int nch = 64 * len / epc, cpt = (nch + 511) / 512;
+            const std::string I = std::to_string(i);
+            src += "    const VT* src" + I + " = (const VT*)(in" + I + " + item0 * " + std::to_string(len) + ");\n";
+            for (int k = 0; k < cpt; ++k)
+                src += "    VT r" + I + "_" + std::to_string(k) + "; if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") r" + I + "_" + std::to_string(k) +
+                       " = __builtin_nontemporal_load(src" + I + " + tid + " + std::to_string(512 * k) + ");\n";
+        }
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const Step::FusedInput& fi = f.fused_inputs[i];
+            const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
+            const int nch = 64 * len / epc, cpt = (nch + 511) / 512;
+            const std::string I = std::to_string(i), L = std::to_string(len);
+            for (int k = 0; k < cpt; ++k) {
+                src += "    if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") {\n";
+                for (int j = 0; j < epc; ++j)
+                    src += "      { const int e = (tid + " + std::to_string(512 * k) + ") * " + std::to_string(epc) + " + " + std::to_string(j) + ", i2 = e / " + L + ", c = e - i2 * " + L +
+                           "; const T v = r" + I + "_" + std::to_string(k) + "[" + std::to_string(j) + "]; slab[i2 * " + std::to_string(stride) + " + " + std::to_string(fi.base) +
+                           " + c] = " + (fi.canon ? "T(0) + v" : "v") + "; }\n";
+                src += "    }\n";
+            }
+        }
+        src += "  } else {\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const Step::FusedInput& fi = f.fused_inputs[i];
             const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
             const std::string I = std::to_string(i), L = std::to_string(len);
-            src += "#pragma unroll 4\n  for (int e = tid; e < " + std::to_string(64 * len) + "; e += 512) { const int i2 = e / " + L + ", c = e - i2 * " + L +
+            src += "#pragma unroll 4\n    for (int e = tid; e < " + std::to_string(64 * len) + "; e += 512) { const int i2 = e / " + L + ", c = e - i2 * " + L +
                    "; T v = i2 < nitems ? in" + I + "[(item0 + i2) * s" + I + " + c] : T(0); slab[i2 * " + std::to_string(stride) + " + " +
                    std::to_string(fi.base) + " + c] = " + (fi.canon ? "T(0) + v" : "v") + "; }\n";
         }
+        src += "  }\n";
         src += "  T* const my = slab + lane * " + std::to_string(stride) + ";\n";
         src += "  __syncthreads();\n";
         for (const Step& s : plan.steps) {
@@ -1659,9 +1698,23 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
             src += "    default: break;\n  }\n  __syncthreads();\n";
         }
         const int out_len = int(plan.out_layout.row_len);
-        src += "#pragma unroll 4\n  for (int e = tid; e < " + std::to_string(64 * out_len) + "; e += 512) { const int i2 = e / " + std::to_string(out_len) +
-               ", c = e - i2 * " + std::to_string(out_len) + "; if (i2 < nitems) out[(item0 + i2) * so + c] = slab[i2 * " + std::to_string(stride) +
-               " + " + std::to_string(out_base) + " + c]; }\n";
+        {
+            const int nch = 64 * out_len / epc, cpt = (nch + 511) / 512;
+            const std::string OL = std::to_string(out_len);
+            src += "  if (nitems == 64 && so == " + OL + " && (((unsigned long long)out) & 15ull) == 0 && " + ((64 * out_len) % epc == 0 && cpt <= 24 ? "true" : "false") + ") {\n";
+            src += "    VT* dst = (VT*)(out + item0 * " + OL + ");\n";
+            for (int k = 0; k < cpt; ++k) {
+                src += "    if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") { VT v;\n";
+                for (int j = 0; j < epc; ++j)
+                    src += "      { const int e = (tid + " + std::to_string(512 * k) + ") * " + std::to_string(epc) + " + " + std::to_string(j) + ", i2 = e / " + OL + ", c = e - i2 * " + OL +
+                           "; v[" + std::to_string(j) + "] = slab[i2 * " + std::to_string(stride) + " + " + std::to_string(out_base) + " + c]; }\n";
+                src += "      __builtin_nontemporal_store(v, dst + tid + " + std::to_string(512 * k) + "); }\n";
+            }
+            src += "  } else {\n";
+            src += "#pragma unroll 4\n    for (int e = tid; e < " + std::to_string(64 * out_len) + "; e += 512) { const int i2 = e / " + OL + ", c = e - i2 * " + OL +
+                   "; if (i2 < nitems) out[(item0 + i2) * so + c] = slab[i2 * " + std::to_string(stride) + " + " + std::to_string(out_base) + " + c]; }\n";
+            src += "  }\n";
+        }
         src += "}\n";
         f.jit_threads = 512;
         f.jit_items = 64;
@@ -1907,10 +1960,17 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     else if (used + rows1 * w1 * 4 <= lds_cap) ent1_mode = 1, used += rows1 * w1 * 4;
     else ent1_mode = 0;
     used = (used + 15) / 16 * 16;
+    // TOLERANCE MODE (without GAAST_FLAG_EXACT_ORDER, like the dense products): a long row of list 2 is cut into `split` slices of
+    // consecutive terms, each summed by a lane of its own in the reference's order, the partial sums added in slice order at the end --
+    // the few long chains that leave most of the workgroup idle become split x as many, half as long.  |error| <= 4 eps sum |terms|
+    // per component (the dense path's contract; one extra rounding per slice).  GAAST_FLAG_EXACT_ORDER: split = 1, bit for bit.
+    int64_t split = 1;
+    if (!(plan.flags & GAAST_FLAG_EXACT_ORDER))
+        while (split < 4 && w2 % (2 * split) == 0 && w2 / (2 * split) >= 32 && rows2 * ipb * 2 * split <= 1024 && rows2 * 2 * split <= mid) split *= 2;
     // one workgroup per CU (the usual case from n = 9 on): 512 threads -- list 1 and the staging have work for all of them, list 2
-    // (few long rows) for rows2 * ipb lanes; two or more workgroups per CU: 256 threads each
+    // (few long rows) for rows2 * split * ipb lanes; two or more workgroups per CU: 256 threads each
     int64_t threads = 2 * used <= lds_cap ? 256 : 512;
-    threads = std::max<int64_t>(threads, std::min<int64_t>(1024, (rows2 * ipb + 63) / 64 * 64));
+    threads = std::max<int64_t>(threads, std::min<int64_t>(1024, (rows2 * split * ipb + 63) / 64 * 64));
     const int64_t w1s = ent1_mode == 1 ? w1 : w1p;   // words per row of list 1's table
     // tables
     c.cj_ent1.assign(size_t(rows1 * w1s), 0u);
@@ -1957,7 +2017,8 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     bool pos1_linear = true;   // row k of list 1 is component k of the mid row (the usual case): no table, no load
     for (int64_t row = 0; row < rows1; ++row) pos1_linear = pos1_linear && int64_t(w.u32_b[size_t(row)]) == row;
     def("POS1_LINEAR", pos1_linear ? 1 : 0);
-    def("PASSES2", (rows2 + threads / ipb - 1) / (threads / ipb));   // rows of list 2 per thread
+    def("SPLIT", split); def("WS", w2 / split);                    // slices per row of list 2, terms per slice
+    def("PASSES2", (rows2 * split + threads / ipb - 1) / (threads / ipb));   // (row, slice) pairs of list 2 per thread
     // terms of list 2 in flight per register set: the registers of two waves per SIMD (512 threads) hold 8 f64 / 16 f32 terms twice; more
     // threads (a single list with many rows x items), fewer registers each
     def("TB", (plan.dtype == GAAST_F32 ? 16 : 8) / (threads > 512 ? 2 : 1));
@@ -2074,11 +2135,11 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     };
     u32 oo_reg[PASSES2];   // this thread's rows of list 2: their output offsets, loaded once
 #pragma unroll
-    for (int k = 0; k < PASSES2; ++k) oo_reg[k] = sub + k * NSUB < ROWS2 ? out2[sub + k * NSUB] : 0u;
+    for (int k = 0; k < PASSES2; ++k) oo_reg[k] = sub + k * NSUB < ROWS2 * SPLIT ? out2[(sub + k * NSUB) / SPLIT] : 0u;
 #if INIT_SRC
     u32 io_reg[PASSES2];   // ... and where their accumulators start from: 0.0 + init[offset] (a covering copy_grades_from folded in)
 #pragma unroll
-    for (int k = 0; k < PASSES2; ++k) io_reg[k] = sub + k * NSUB < ROWS2 ? pos1[sub + k * NSUB] : 0u;
+    for (int k = 0; k < PASSES2; ++k) io_reg[k] = sub + k * NSUB < ROWS2 * SPLIT ? pos1[(sub + k * NSUB) / SPLIT] : 0u;
 #endif
     const long long groups = (batch + IPB - 1) / IPB;
     // register-prefetch staging needs contiguous, 16-byte aligned rows (wave-uniform test); shared rows (stride 0), wrapped
@@ -2163,11 +2224,11 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
 #if BETA
         T acc0[PASSES2];   // list 2 adds into what another arm left in `out`: read BEFORE the prefetch is issued (in-order counter)
 #pragma unroll
-        for (int k = 0; k < PASSES2; ++k) acc0[k] = (sub + k * NSUB < ROWS2 && it < nitems) ? out[(item0 + it) * s_out + oo_reg[k]] : T(0);
+        for (int k = 0; k < PASSES2; ++k) acc0[k] = (sub + k * NSUB < ROWS2 * SPLIT && it < nitems) ? out[(item0 + it) * s_out + oo_reg[k]] : T(0);
 #elif INIT_SRC
         T acc0[PASSES2];   // ... or onto a copy of an input's grades, made here: 0.0 + x (graded.rs:195-201 then :74)
 #pragma unroll
-        for (int k = 0; k < PASSES2; ++k) acc0[k] = T(0) + ((sub + k * NSUB < ROWS2 && it < nitems) ? init[(item0 + it) * s_init + io_reg[k]] : T(0));
+        for (int k = 0; k < PASSES2; ++k) acc0[k] = T(0) + ((sub + k * NSUB < ROWS2 * SPLIT && it < nitems) ? init[(item0 + it) * s_init + io_reg[k]] : T(0));
 #endif
         if (pre_next) issue(gn * IPB);   // in flight while this group is evaluated
         // ---- list 1 -> mid (eval.rs:77-83 into the fresh cache buffer of eval.rs:21-33): the operands of row k + 1 are in
@@ -2212,24 +2273,30 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
         __syncthreads();
 #endif
         // ---- list 2: (mid, other operand) -> out; TB terms' operands in flight while the previous TB are summed ----
+#if SPLIT > 1
+        T part[PASSES2];
+#endif
 #pragma unroll
         for (int pass = 0; pass < PASSES2; ++pass) {
-            const int row = sub + pass * NSUB;
-            if (row >= ROWS2) break;
+            const int vrow = sub + pass * NSUB;          // (row, slice)
+            if (vrow >= ROWS2 * SPLIT) break;
+            const int row = vrow / SPLIT, slice = vrow % SPLIT;
             const u32 oo = oo_reg[pass];
-#if BETA || INIT_SRC
+#if (BETA || INIT_SRC) && SPLIT == 1
             T acc = acc0[pass];
 #else
-            T acc = T(0);
+            T acc = T(0);                                // (slices start from zero: what the row adds onto joins them at the end)
 #endif
-            constexpr int NB = W2 / TB;                  // batches of TB terms
+            constexpr int NB = WS / TB;                  // batches of TB terms
+            constexpr int QPT = ENT2_MODE == 2 ? 2 : 4;  // terms per table quad
+            const int q0 = slice * (WS / QPT);           // the slice's first quad (WS is a multiple of 4)
 #if ENT2_MODE == 2
             T ma[TB], oa[TB], mb[TB], ob[TB];
             u32 sa[TB], sb[TB];
             auto load2 = [&](T (&mv)[TB], T (&ov)[TB], u32 (&sg)[TB], int b) {
 #pragma unroll
                 for (int q = 0; q < TB / 2; ++q) {
-                    const u32x4 e4 = ent2_quad(row, (TB / 2) * b + q);
+                    const u32x4 e4 = ent2_quad(row, q0 + (TB / 2) * b + q);
                     mv[2 * q] = LDS(base + (e4[0] & 0xffffu));
                     ov[2 * q] = LDS(base + (e4[0] >> 16));
                     sg[2 * q] = e4[1];
@@ -2250,7 +2317,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             auto load2 = [&](T (&mv)[TB], T (&ov)[TB], T (&sg)[TB], int b) {
 #pragma unroll
                 for (int q = 0; q < TB / 4; ++q) {
-                    const u32x4 e4 = ent2_quad(row, (TB / 4) * b + q);
+                    const u32x4 e4 = ent2_quad(row, q0 + (TB / 4) * b + q);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         mv[4 * q + j] = LDS(base + (e4[j] & 0xffffu));
@@ -2277,19 +2344,47 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             }
             if (NB & 1) sum2(ma, oa, sa);
 #pragma unroll
-            for (int t = NB * TB; t < W2; ++t) {         // the remainder (compile-time count, no padding terms)
+            for (int t = NB * TB; t < WS; ++t) {         // the remainder (compile-time count, no padding terms)
 #if ENT2_MODE == 2
-                const u32x4 e4 = ent2_quad(row, t / 2);
+                const u32x4 e4 = ent2_quad(row, q0 + t / 2);
                 const u32 e = e4[2 * (t & 1)], sgb = e4[2 * (t & 1) + 1];
                 const T pr_ = LDS(base + (e & 0xffffu)) * LDS(base + (e >> 16));
                 acc = acc + with_hi(pr_, hi_of(pr_) ^ sgb);
 #else
-                const u32 e = ent2_quad(row, t / 4)[t & 3];
+                const u32 e = ent2_quad(row, q0 + t / 4)[t & 3];
                 acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), pm_one((e & 0x80000000u) | ONE_HI), acc);
 #endif
             }
+#if SPLIT > 1
+            part[pass] = acc;
+#else
             if (it < nitems) out[(item0 + it) * s_out + oo] = acc;
+#endif
         }
+#if SPLIT > 1
+        // the slices of a row meet through LDS (the mid rows are dead by now): partial sums in slice order onto the row's start value
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < PASSES2; ++pass) {
+            const int vrow = sub + pass * NSUB;
+            if (vrow < ROWS2 * SPLIT) *(__attribute__((address_space(3))) T*)(smem + base + OFF_MID + vrow * ESZ) = part[pass];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < PASSES2; ++pass) {
+            const int vrow = sub + pass * NSUB;
+            if (vrow < ROWS2 * SPLIT && vrow % SPLIT == 0 && it < nitems) {
+#if BETA || INIT_SRC
+                T acc = acc0[pass];
+#else
+                T acc = T(0);
+#endif
+#pragma unroll
+                for (int sl = 0; sl < SPLIT; ++sl) acc = acc + LDS(base + OFF_MID + (vrow + sl) * ESZ);
+                out[(item0 + it) * s_out + oo_reg[pass]] = acc;
+            }
+        }
+#endif
         __syncthreads();   // the rows are rewritten by the next group
         if (!more) break;
         g = gn;
@@ -2304,6 +2399,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     for (int i = 0; i < 7; ++i) c.cj_layout[i] = int(lay[i]);
     c.cj_fmt[0] = int(w1s);
     c.cj_fmt[1] = ent2_mode;
+    c.cj_split = int(split);
     c.cj_ipb = int(ipb);
     c.cj_threads = int(threads);
     c.cj_lds = size_t(used);
@@ -2409,6 +2505,82 @@ static void chain_list_into_list(Plan& plan) {
     for (Step& t : plan.steps)
         if (!(t.kind == Step::ZERO && t.res.kind == BufKind::NODE && t.res.idx < 0)) kept.push_back(std::move(t));
     plan.steps = std::move(kept);
+}
+
+// x (*) f(<l, r>): a product into ONE scalar component (a single row: norm_sq), an optional ScalarUnaryOp on it, and a product of
+// one-term rows that multiplies another row by that scalar -- a.rev() * a.norm_sq().sinv(), the versor inverse of expr.rs:363-371,
+// where the rows no longer fit a fused slab -- become ONE k_reduce_scale launch (kernels_exact.hip.hpp): reference order and
+// roundings, the scalar never leaves the wave, the row is streamed once from HBM.  Runs on the CSR form, before the ELL pass.
+static void fuse_reduce_scale(Plan& plan) {
+    if (plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_DEBUG_NO_CHAIN)) return;
+    auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
+    for (size_t i = 0; i + 1 < plan.steps.size(); ++i) {
+        Step& p1 = plan.steps[i];
+        if (p1.kind != Step::PRODUCT_CSR || p1.u32_b.size() != 1 || p1.beta != 0 || p1.res.kind != BufKind::NODE || p1.list_chain || p1.chained) continue;
+        if (plan.node_buffers[size_t(p1.res.idx)].row_len != 1 || p1.u32_c.size() < 64) continue;
+        const BufRef S = p1.res;
+        size_t j = i + 1;
+        int op = 0;
+        if (plan.steps[j].kind == Step::SUNARY && same(plan.steps[j].res, S) && plan.steps[j].sunary_off == 0) {
+            op = plan.steps[j].sunary_op == 0 ? 1 : 2;
+            ++j;
+        }
+        if (j >= plan.steps.size()) continue;
+        Step& p2 = plan.steps[j];
+        if (p2.kind != Step::PRODUCT_CSR || p2.beta != 0 || p2.list_chain || p2.chained) continue;
+        const bool s_left = same(p2.a, S), s_right = same(p2.b, S);
+        if (s_left == s_right) continue;
+        const BufRef xop = s_left ? p2.b : p2.a;
+        if (same(xop, S) || same(p2.res, p1.a) || same(p2.res, p1.b) || same(p2.res, xop)) continue;
+        bool ok = true;
+        for (size_t r = 0; r + 1 < p2.u32_a.size() && ok; ++r) ok = p2.u32_a[r + 1] - p2.u32_a[r] == 1;   // one term per row
+        for (size_t k = 0; k < plan.steps.size() && ok; ++k) {   // nobody else touches the scalar
+            if (k == i || k == j || (op && k == i + 1)) continue;
+            const Step& t = plan.steps[k];
+            if (same(t.res, S) || (t.a.idx >= 0 && same(t.a, S)) || (t.b.idx >= 0 && same(t.b, S))) ok = false;
+            if ((t.chained || t.list_chain) && (same(t.pre_a, S) || same(t.pre_b, S))) ok = false;
+        }
+        if (!ok) continue;
+        Step f;
+        f.kind = Step::REDUCE_SCALE;
+        f.res = p2.res;
+        f.a = p1.a;
+        f.b = p1.b;
+        f.pre_a = xop;
+        f.canon_a = p1.canon_a;
+        f.canon_b = p1.canon_b;
+        f.pre_canon_a = s_left ? p2.canon_b : p2.canon_a;
+        f.rs_canon_s = s_left ? p2.canon_a : p2.canon_b;
+        f.rs_op = op;
+        f.list_chain = s_left ? 1 : 2;   // (which side of the scaling the scalar is on; run_step reads it)
+        f.u32_a = p1.u32_c;
+        f.coeff = p1.coeff;
+        f.u32_b.resize(p2.u32_c.size());
+        f.coeff_b = p2.coeff;
+        for (size_t r = 0; r + 1 < p2.u32_a.size(); ++r) {
+            const uint32_t e = p2.u32_c[p2.u32_a[r]];
+            const uint32_t xoff = s_left ? (e >> 16) : (e & 0xffffu);
+            f.u32_b[r] = xoff | (p2.u32_b[r] << 16);
+        }
+        f.beta = 0;
+        f.n_entries = p1.n_entries + p2.n_entries;
+        f.name = "reduce_scale[" + std::to_string(p1.u32_c.size()) + " comp-muls -> scalar" + (op == 1 ? ", 1/s" : op == 2 ? ", sqrt(s)" : "") + ", " +
+                 std::to_string(p2.u32_c.size()) + " scaled components]";
+        if (plan.node_dead.size() != plan.node_buffers.size()) plan.node_dead.assign(plan.node_buffers.size(), 0);
+        plan.node_dead[size_t(S.idx)] = 1;
+        // out offsets need 16 bits
+        bool fits = true;
+        for (uint32_t o : p2.u32_b) fits = fits && o < 65536u;
+        if (!fits) continue;
+        std::vector<Step> kept;
+        for (size_t k = 0; k < plan.steps.size(); ++k) {
+            if (k == i) kept.push_back(std::move(f));
+            else if (k == j || (op && k == i + 1)) continue;
+            else kept.push_back(std::move(plan.steps[k]));
+        }
+        plan.steps = std::move(kept);
+        return fuse_reduce_scale(plan);   // (indices moved: look again for another instance)
+    }
 }
 
 // A list with FEW LONG rows that stayed a launch of its own -- b * c projected on a low grade: (a + b * c).g(2) at n = 8 is 28 rows of 256
@@ -2524,6 +2696,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
         }
     }
     if (!try_fuse(plan)) {
+        fuse_reduce_scale(plan);
         chain_sparse_into_dense(plan);
         uniform_csr_to_ell(plan);
         chain_list_into_list(plan);

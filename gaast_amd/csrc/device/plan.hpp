@@ -35,7 +35,7 @@ inline Layout make_layout(int dim, uint64_t mask) {
 }
 
 struct Step {
-    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG } kind = ZERO;
+    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG, REDUCE_SCALE } kind = ZERO;
     BufRef res, a, b;
     std::string name;
     std::string hip_kernel;        // the HIP kernel (template and arguments) prepare_step picked: appended to the launch label
@@ -117,11 +117,19 @@ struct Step {
     int fold_prev = 0;                   // ... and, once compiled, also the covering copy_grades_from step right before it (pre_a = its source)
     int cj_ipb = 0, cj_threads = 0;
     size_t cj_lds = 0;
+    int cj_split = 1;                            // slices per row of list 2 (> 1: re-ordered sums, tolerance mode; 1 with GAAST_FLAG_EXACT_ORDER)
     int cj_fmt[2] = {0, 0};                     // words per row of list 1's table; list 2's entries: 2 = wide (8 bytes: offsets, then the sign bit), else narrow
     int cj_layout[7] = {0, 0, 0, 0, 0, 0, 0};   // an item in LDS, elements: offsets of l1, r1, the negated image, mid, r2 (-1: aliased); item stride; negated image is of the left operand
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9
     int use_mfma16d = 0; // (same; kept apart from use_mfma16 since round 2's four-items-per-instruction kernel shared the first)
+    // REDUCE_SCALE (plan.cpp: fuse_reduce_scale): a product whose result is ONE scalar component (a single long row: norm_sq), an
+    // optional ScalarUnaryOp on it, and a product of one-term rows that multiplies another row by that scalar -- the versor inverse
+    // a.rev() * a.norm_sq().sinv() and normalisations, where the rows no longer fit a fused slab (n >= 9) -- in ONE launch, one wave per
+    // item: u32_a / coeff = the reduction's terms in the reference's order (left | right << 16, coefficient), a / b = its operands;
+    // u32_b / coeff_b = the scaling's rows (operand offset | result offset << 16, coefficient), pre_a = its row operand.
+    int rs_op = 0;                       // 0: none, 1: 1 / s, 2: sqrt(s)  (eval.rs:103-110)
+    int rs_canon_s = 0;                  // the scalar is re-read as a product operand: 0.0 + s
     int use_mfma6 = 0;   // k_gp_mfma6<T> (n = 6: four 16x16x4 instructions per item, the two top vectors split over the tile's rows and columns)
     int use_mfma7 = 0;   // k_gp_mfma7<T> (n = 7: lo = 3 bits, the top vector split over the two sides of the 16 x 16 tile)
     int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout

@@ -226,7 +226,8 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             // the chain (or single long-row list) specialised through hiprtc (plan.cpp: make_chain_jit): static LDS, persistent workgroups
             s.threads = s.cj_threads;
             s.lds = s.cj_lds;
-            s.hip_kernel = "gaast_chain<" + tn + ">[" + (s.list_jit ? "one list, " : "") + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads]";
+            s.hip_kernel = "gaast_chain<" + tn + ">[" + (s.list_jit ? "one list, " : "") + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads" +
+                           (s.cj_split > 1 ? ", rows in " + std::to_string(s.cj_split) + " slices: re-ordered sums" : "") + "]";
             int per_cu = 0;
             HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, static_cast<hipFunction_t>(s.jit_function), s.threads, 0));
             s.blocks_per_cu = per_cu < 1 ? 1 : per_cu;
@@ -416,6 +417,12 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
     }
+    case Step::REDUCE_SCALE: {
+        s.threads = 256;
+        s.kern[0] = reinterpret_cast<const void*>(&k_reduce_scale<T>);
+        s.hip_kernel = "k_reduce_scale<" + tn + ">";
+        return resident_blocks(s.kern[0], s.threads, 0, &s.blocks_per_cu);
+    }
     case Step::FUSED: {
         if (s.jit_function) return GAAST_OK;
         const size_t lds = (size_t(s.fused_slab) * FUSED_ITEMS + 8) * sizeof(T);
@@ -447,6 +454,35 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         hipLaunchKernelGGL(k_scalar_unary<T>, dim3(grid_for(batch, 256)), dim3(256), 0, g_stream,
                            static_cast<T*>(res.ptr), res.stride, s.sunary_off, s.sunary_op, batch);
         break;
+    case Step::REDUCE_SCALE: {
+        ReduceScaleArgs<T> q;
+        q.l1 = static_cast<const T*>(a.ptr);
+        q.r1 = static_cast<const T*>(b.ptr);
+        q.x = static_cast<const T*>(pre_a.ptr);
+        q.out = static_cast<T*>(res.ptr);
+        q.l1_stride = a.stride;
+        q.r1_stride = b.stride;
+        q.x_stride = pre_a.stride;
+        q.out_stride = res.stride;
+        q.ent1 = static_cast<const uint32_t*>(s.d_a);
+        q.coeff1 = static_cast<const T*>(s.d_coeff);
+        q.ent2 = static_cast<const uint32_t*>(s.d_b);
+        q.coeff2 = static_cast<const T*>(s.d_coeff_b);
+        q.n1 = int(s.u32_a.size());
+        q.n2 = int(s.u32_b.size());
+        q.canon_l1 = s.canon_a;
+        q.canon_r1 = s.canon_b;
+        q.canon_x = s.pre_canon_a;
+        q.canon_s = s.rs_canon_s;
+        q.s_is_left = s.list_chain == 1;
+        q.op = s.rs_op;
+        q.batch = batch;
+        // sixteen items per wave, four waves per workgroup, persistent: as many workgroups as are resident at once
+        int64_t blocks = (batch + 63) / 64;
+        blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * (s.blocks_per_cu > 0 ? s.blocks_per_cu : 8));
+        hipLaunchKernelGGL(k_reduce_scale<T>, dim3(unsigned(blocks)), dim3(256), 0, g_stream, q);
+        break;
+    }
     case Step::EXPLOG: {
         ExpLogArgs<T> q;
         q.res = static_cast<T*>(res.ptr);
@@ -998,7 +1034,9 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             if (int st = upload_t(s.pre_coeff, &s.d_pre_coeff)) return st;
             if (int st = upload_t(s.pre_row_scale, &s.d_pre_row_scale)) return st;
         }
-        if (s.list_chain || s.list_jit) {
+        if (s.kind == Step::REDUCE_SCALE) {
+            if (s.pre_a.idx >= 0 && s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
+        } else if (s.list_chain || s.list_jit) {
             if (s.pre_a.idx >= 0 && s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
             if (s.list_chain && s.pre_b.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_b.idx)] = 1;
             if (s.chain_jit == 2) {
@@ -1315,7 +1353,10 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         if (s.b.idx >= 0) b = resolve(s.b, &lb);
         const int step_n = (s.kind == Step::PRODUCT_DENSE && s.dense_n) ? s.dense_n : plan.n;
         Bound pa{nullptr, 0}, pb{nullptr, 0};
-        if (s.chained || s.list_chain) {
+        if (s.kind == Step::REDUCE_SCALE) {
+            Layout unused;
+            pa = resolve(s.pre_a, &unused);
+        } else if (s.chained || s.list_chain) {
             Layout unused;
             pa = resolve(s.pre_a, &unused);
             pb = resolve(s.pre_b, &unused);

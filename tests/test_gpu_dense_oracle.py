@@ -522,18 +522,33 @@ def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
     rows = {0: rows_of(n, even, batch, rng), 1: rows_of(n, [1], batch, rng)}
     alg = metric if any(m != 1.0 for m in metric) else n
     want, wmask = oracle_eval_batch(build, alg, rows, batch)
-    got, mask, spec = hip_eval_batch(build, alg, rows, batch)
+    # GAAST_FLAG_EXACT_ORDER: the reference's summation order, bit for bit
+    got, mask, spec = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_EXACT_ORDER)
     assert mask == wmask
     # the chain specialised per program through hiprtc (round 4) ...
     assert len(spec.launches()) == 1 and "<- product_" in spec.launches()[0] and "gaast_chain<double>" in spec.launches()[0], spec.launches()
+    assert "re-ordered" not in spec.launches()[0]
     assert np.array_equal(got, want)
     # ... and the generic kernel it falls back to without run-time compilation (n = 8 without hiprtc: the LDS interpreter)
     gen, _, spec3 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_NO_JIT)
     assert len(spec3.launches()) == 1 and np.array_equal(gen, want), spec3.launches()
     if n > 8:
         assert "k_product_ell_chain<double>" in spec3.launches()[0], spec3.launches()
-    two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN)
-    assert len(spec2.launches()) == (2 if n > 8 else 1) and np.array_equal(two, want), spec2.launches()    # (n = 8 without the chain: the interpreter)
+    two, _, spec2 = hip_eval_batch(build, alg, rows, batch, flags=ga.FLAG_DEBUG_NO_CHAIN | ga.FLAG_EXACT_ORDER)
+    assert len(spec2.launches()) == (2 if n > 8 else 1) and np.array_equal(two, want), spec2.launches()    # (n = 8 without the chain: one fused launch)
+    # DEFAULT (tolerance mode, like the dense products): the long rows of the second list are cut into slices summed by lanes of
+    # their own -- "wavefront-parallel partial sums" -- within 4 eps sum |terms| of the oracle, per component
+    tol, tmask, spec4 = hip_eval_batch(build, alg, rows, batch)
+    assert tmask == wmask and len(spec4.launches()) == 1 and "gaast_chain<double>" in spec4.launches()[0], spec4.launches()
+    if n <= 10:
+        assert "re-ordered sums" in spec4.launches()[0], spec4.launches()
+    mid, mmask = oracle_eval_batch(lambda B: B.input(0, even, n) * B.input(1, [1], n), alg, rows, batch)
+    odd = [k for k in range(n + 1) if (mmask >> k) & 1]
+    for i in range(batch):
+        S = abs_terms_bound(n, row_to_bits(n, odd, mid[i]), row_to_bits(n, even, rows[0][i]))
+        bound = 4 * 2.0 ** -52 * bits_to_row(n, [1], S) + 1e-300
+        err = np.abs(tol[i] - want[i])
+        assert np.all(err <= bound), (i, float((err / bound).max()))
 
 
 @pytest.mark.parametrize("dtype", [ga.F64, ga.F32])
@@ -552,8 +567,8 @@ def test_list_chains_with_the_mid_row_on_either_side_and_unrelated_operands(dtyp
     all_rows = rows
     for k, build in enumerate(cases):
         rows = {s_: all_rows[s_] for s_ in ((0, 1, 2), (0, 1, 2), (0, 1, 3))[k]}
-        got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
-        two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
+        got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_EXACT_ORDER)
+        two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN | ga.FLAG_EXACT_ORDER)
         assert np.array_equal(got, two), (k, spec.launches(), spec2.launches())
         if not any("ast_fused" in l or "ast_jit" in l for l in spec.launches()):     # (f32 slabs of the third program fit a fused launch: one launch anyway)
             assert any("gaast_chain<" in l for l in spec.launches()), (k, spec.launches())
@@ -621,3 +636,59 @@ def test_n7_parity_pure_products_run_in_cl6_on_the_matrix_cores():
         _check(n, [1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0], grades[lpar],
                [(ga.F32, 0, "product_dense_mfma[", "k_gp_mfma6<float,false,"), (ga.F64, 0, "product_dense_mfma[", "k_gp_mfma6<double,false,")],
                batch=33, seed=770, right_grades=grades[rpar], label_has=f"{lpar} x {rpar} in Cl(6)")
+
+
+@pytest.mark.parametrize("n,dtype,metric", [(9, ga.F64, None), (10, ga.F32, None), (12, ga.F64, None), (9, ga.F64, [1.0, -1.0, 2.0, 1.0, 0.5, -1.0, 1.0, -4.0, 1.0])])
+def test_the_versor_inverse_beyond_a_fused_slab_is_one_launch(n, dtype, metric):
+    """a.vinv() = a.rev() * a.norm_sq().sinv() (expr.rs:363-371), a even, where the rows no longer fit a fused slab: round 3 ran three
+    launches (a product into one scalar component -- a single row of 2^(n-1) terms on a thread-per-row kernel --, k_scalar_unary, a
+    product of one-term rows).  Round 4: ONE k_reduce_scale launch -- reduction in the reference's order, correctly rounded division,
+    scaling -- bit for bit the oracle (f32: its F32 mode) and the unfused plan; also with a general diagonal metric (coefficients
+    other than +-1 in both products)."""
+    even = EVEN(n)
+    build = lambda B: B.input(0, even, n).vinv()
+    batch = 41
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(300 + n)
+    rows = {0: rows_of(n, even, batch, rng, npdt)}
+    rows64 = {0: rows[0].astype(np.float64)}
+    alg = metric if metric else n
+    want, wmask = oracle_eval_batch(build, alg, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
+    got, mask, spec = hip_eval_batch(build, alg, rows, batch, dtype=dtype)
+    assert mask == wmask
+    assert len(spec.launches()) == 1 and spec.launches()[0].startswith("reduce_scale[") and "k_reduce_scale<" in spec.launches()[0], spec.launches()
+    assert np.array_equal(got.astype(np.float64), want)
+    three, _, spec3 = hip_eval_batch(build, alg, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
+    assert len(spec3.launches()) == 3 and np.array_equal(three.astype(np.float64), want), spec3.launches()
+    assert any("k_scalar_unary" in l or "scalar_inversion" in l for l in spec3.launches()), spec3.launches()
+
+
+@pytest.mark.parametrize("name,dtype", [("vinv8", ga.F64), ("vinv8", ga.F32), ("proj12", ga.F64), ("unary12", ga.F64)])
+def test_medium_programs_run_as_straight_line_code_over_slabs_in_lds(name, dtype):
+    """Programs whose slab is beyond the registers of the specialised kernel (160 / 200 elements) but short (<= 2048 comp-muls): the
+    interpreter's schedule as hiprtc-compiled straight-line code over slabs that stay in LDS (round 4; the LDS interpreter remains the
+    fallback).  The versor inverse at n = 8 (slab 259), the projection KAT of eval.rs:152-163 at n = 12 (slab 171), and a chain of
+    unary arms (Negation, Reverse, GradeInvolution, Addition) over bivector rows at n = 12: bit for bit the oracle and the interpreter."""
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(77)
+    batch = 131
+    if name == "vinv8":
+        n = 8
+        build = lambda B: B.input(0, EVEN(n), n).vinv()
+        rows = {0: rows_of(n, EVEN(n), batch, rng, npdt)}
+    elif name == "proj12":
+        n = 12
+        build = lambda B: (lambda v, bv: (v & bv) & bv.vinv())(B.input(0, [1], n), B.input(1, [2], n))
+        rows = {0: rows_of(n, [1], batch, rng, npdt), 1: rows_of(n, [2], batch, rng, npdt)}
+    else:
+        n = 12
+        build = lambda B: (-(B.input(0, [2], n).rev()) + B.input(1, [2], n).ginvol()).rev() * B.input(2, [0], n)
+        rows = {0: rows_of(n, [2], batch, rng, npdt), 1: rows_of(n, [2], batch, rng, npdt), 2: rows_of(n, [0], batch, rng, npdt)}
+    rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+    want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
+    got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+    assert mask == wmask
+    assert len(spec.launches()) == 1 and spec.launches()[0].startswith("ast_jit[") and "slab in LDS" in spec.launches()[0], spec.launches()
+    assert np.array_equal(got.astype(np.float64), want)
+    interp, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT)
+    assert len(spec2.launches()) == 1 and spec2.launches()[0].startswith("ast_fused[") and np.array_equal(interp.astype(np.float64), want), spec2.launches()

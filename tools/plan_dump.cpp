@@ -9,6 +9,7 @@
 #include "gaast_expr.h"
 #include "plan.hpp"
 
+static const char* g_dump_dir = nullptr;   // argv[2]: write the generated kernel sources there
 static uint64_t full_mask(int n) { return (uint64_t(2) << n) - 1; }
 static uint64_t even_mask(int n) { return 0x5555555555555555ull & full_mask(n); }
 
@@ -25,12 +26,23 @@ static void dump(const char* what, gaast_expr_t e, int n, int dtype, uint32_t fl
     gaast::build_plan(desc, plan);
     std::printf("%s (n = %d, %s, flags 0x%x): %zu step(s), %zu cache buffer(s)%s\n", what, n, dtype == GAAST_F32 ? "f32" : "f64", flags,
                 plan.steps.size(), plan.node_buffers.size(), plan.unsupported.empty() ? "" : (" UNSUPPORTED: " + plan.unsupported).c_str());
-    for (const gaast::Step& s : plan.steps) std::printf("    %s%s\n", s.name.c_str(), s.chain_jit ? "  [gaast_chain]" : "");
+    for (const gaast::Step& s : plan.steps) {
+        std::printf("    %s%s%s\n", s.name.c_str(), s.chain_jit ? "  [gaast_chain]" : "", s.jit_source.empty() ? "" : (s.jit_items ? "  [gaast_jit, slab in LDS]" : "  [gaast_jit]"));
+        if (g_dump_dir && !s.jit_source.empty()) {
+            char path[512];
+            std::snprintf(path, sizeof path, "%s/%s_n%d.hip", g_dump_dir, what, n);
+            if (FILE* f = std::fopen(path, "w")) {
+                std::fputs(s.jit_source.c_str(), f);
+                std::fclose(f);
+            }
+        }
+    }
     gaast_spec_free(spec);
 }
 
 int main(int argc, char** argv) {
     const uint32_t flags = argc > 1 ? uint32_t(std::strtoul(argv[1], nullptr, 0)) : 0u;
+    g_dump_dir = argc > 2 ? argv[2] : nullptr;
     for (int n : {8, 12}) {
         {   // vinv: a.rev() * a.norm_sq().sinv(), a even (expr.rs:363-371)
             gaast_expr_t a = gaast_expr_input(0, even_mask(n), n);
