@@ -1576,14 +1576,14 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
         src += "T* __restrict__ out, long long so, long long batch) {\n";
         src += "  __shared__ T slab[" + std::to_string(64 * stride) + "];\n";
         src += "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n";
-        src += "  const long long item0 = blockIdx.x * 64LL;\n";
-        src += "  const int nitems = int(batch - item0 < 64 ? batch - item0 : 64);\n";
+        src += "  T* const my = slab + lane * " + std::to_string(stride) + ";\n";
         // inputs: element e = item * len + c of the flattened range.  Contiguous, 16-byte aligned rows of a full group of 64 items are
-        // moved as 16-byte pieces, ALL of them in flight before the first is written to LDS (a group is 64 KiB at slab 259: the
-        // HBM latency is paid once); anything else -- shared rows, strided wrapped memory, the last partial group -- takes a plain loop
+        // moved as 16-byte pieces through registers, ALL of them in flight at once, and -- the workgroups are persistent -- the NEXT
+        // group's pieces are requested before this group is evaluated (a group is 64 KiB at slab 259: the HBM latency hides under
+        // the arithmetic); anything else -- shared rows, strided wrapped memory, the last partial group -- takes a plain loop
         const int epc = int(16 / elem);
         src += std::string("  typedef T VT __attribute__((ext_vector_type(") + std::to_string(epc) + ")));\n";
-        std::string fast_cond = "nitems == 64";
+        std::string fast_cond = "true";
         int total_chunks_per_thread = 0;
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
@@ -1593,16 +1593,26 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
             total_chunks_per_thread += (64 * len / epc + 511) / 512;
         }
         if (total_chunks_per_thread > 24) fast_cond = "false";
-        src += "  if (" + fast_cond + ") {\n";
+        src += "  const bool fast = " + fast_cond + ";\n";
+        src += "  const long long groups = (batch + 63) / 64;\n";
+        for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
+            const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
+            const int nch = 64 * len / epc, cpt = std::max(1, (nch + 511) / 512);
+            src += "  VT r" + std::to_string(i) + "[" + std::to_string(cpt) + "];\n";
+        }
+        src += "  auto issue = [&](long long item0) {\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const int len = int(plan.input_layouts[size_t(f.fused_inputs[i].slot)].row_len);
             const int nch = 64 * len / epc, cpt = (nch + 511) / 512;
             const std::string I = std::to_string(i);
-            src += "    const VT* src" + I + " = (const VT*)(in" + I + " + item0 * " + std::to_string(len) + ");\n";
+            src += "    { const VT* src = (const VT*)(in" + I + " + item0 * " + std::to_string(len) + ");\n";
             for (int k = 0; k < cpt; ++k)
-                src += "    VT r" + I + "_" + std::to_string(k) + "; if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") r" + I + "_" + std::to_string(k) +
-                       " = __builtin_nontemporal_load(src" + I + " + tid + " + std::to_string(512 * k) + ");\n";
+                src += "      if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") r" + I + "[" + std::to_string(k) +
+                       "] = __builtin_nontemporal_load(src + tid + " + std::to_string(512 * k) + ");\n";
+            src += "    }\n";
         }
+        src += "  };\n";
+        src += "  auto commit = [&]() {\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const Step::FusedInput& fi = f.fused_inputs[i];
             const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
@@ -1612,12 +1622,13 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
                 src += "    if (tid + " + std::to_string(512 * k) + " < " + std::to_string(nch) + ") {\n";
                 for (int j = 0; j < epc; ++j)
                     src += "      { const int e = (tid + " + std::to_string(512 * k) + ") * " + std::to_string(epc) + " + " + std::to_string(j) + ", i2 = e / " + L + ", c = e - i2 * " + L +
-                           "; const T v = r" + I + "_" + std::to_string(k) + "[" + std::to_string(j) + "]; slab[i2 * " + std::to_string(stride) + " + " + std::to_string(fi.base) +
+                           "; const T v = r" + I + "[" + std::to_string(k) + "][" + std::to_string(j) + "]; slab[i2 * " + std::to_string(stride) + " + " + std::to_string(fi.base) +
                            " + c] = " + (fi.canon ? "T(0) + v" : "v") + "; }\n";
                 src += "    }\n";
             }
         }
-        src += "  } else {\n";
+        src += "  };\n";
+        src += "  auto stage = [&](long long item0, int nitems) {\n";
         for (size_t i = 0; i < f.fused_inputs.size(); ++i) {
             const Step::FusedInput& fi = f.fused_inputs[i];
             const int len = int(plan.input_layouts[size_t(fi.slot)].row_len);
@@ -1626,9 +1637,18 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
                    "; T v = i2 < nitems ? in" + I + "[(item0 + i2) * s" + I + " + c] : T(0); slab[i2 * " + std::to_string(stride) + " + " +
                    std::to_string(fi.base) + " + c] = " + (fi.canon ? "T(0) + v" : "v") + "; }\n";
         }
-        src += "  }\n";
-        src += "  T* const my = slab + lane * " + std::to_string(stride) + ";\n";
+        src += "  };\n";
+        src += "  long long g = blockIdx.x;\n  if (g >= groups) return;\n";
+        src += "  { const long long item0 = g * 64; const int nitems = int(batch - item0 < 64 ? batch - item0 : 64);\n";
+        src += "    if (fast && nitems == 64) { issue(item0); commit(); } else stage(item0, nitems); }\n";
+        src += "  for (;;) {\n";
+        src += "  const long long item0 = g * 64;\n";
+        src += "  const int nitems = int(batch - item0 < 64 ? batch - item0 : 64);\n";
+        src += "  const long long gn = g + gridDim.x;\n  const bool more = gn < groups;\n";
+        src += "  const int nnext = more ? int(batch - gn * 64 < 64 ? batch - gn * 64 : 64) : 0;\n";
+        src += "  const bool pre_next = fast && more && nnext == 64;\n";
         src += "  __syncthreads();\n";
+        src += "  if (pre_next) issue(gn * 64);\n";
         for (const Step& s : plan.steps) {
             const uint32_t rb = uint32_t(base_of(s.res));
             // the independent pieces of this arm, each a (cost, statements) pair, dealt to the waves least-loaded first
@@ -1715,9 +1735,13 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
                    "; if (i2 < nitems) out[(item0 + i2) * so + c] = slab[i2 * " + std::to_string(stride) + " + " + std::to_string(out_base) + " + c]; }\n";
             src += "  }\n";
         }
+        src += "  if (!more) break;\n  g = gn;\n  __syncthreads();\n";   // the slabs are rewritten for the next group
+        src += "  if (pre_next) commit(); else stage(gn * 64, nnext);\n";
+        src += "  }\n";
         src += "}\n";
         f.jit_threads = 512;
         f.jit_items = 64;
+        f.jit_persistent = int(std::max<size_t>(1, kLdsBytes / (size_t(64) * size_t(stride) * elem)));   // workgroups resident per CU (LDS)
         f.jit_source = std::move(src);
     }
     f.fused_slab = slab;
@@ -1931,7 +1955,7 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     int64_t stride = cur | 1;   // odd: lanes reading one offset of consecutive items touch consecutive banks (bank pairs in f64)
     const int64_t off_other = alias == 0 ? off_r2 : alias == 1 ? off_l1 : off_r1;
     const int64_t other_len = alias == 0 ? r2 : alias == 1 ? l1 : r1;
-    if ((off_other + other_len) * esz > 32768 || stride * esz > 65535) return;
+    if ((off_other + other_len) * esz > 32768 || cur * esz > 65536) return;   // (15-bit / 16-bit byte offsets from the item's base)
     const int64_t rows1 = int64_t(w.u32_b.size()), rows2 = int64_t(c.u32_b.size());
     const int64_t w1 = w.ell_width, w2 = c.ell_width;
     if (rows2 <= 0 || w2 <= 0) return;
@@ -2599,7 +2623,7 @@ static void jit_long_row_lists(Plan& plan) {
         Step& c = plan.steps[j];
         if (c.kind != Step::PRODUCT_CSR || c.ell_width < 32 || !c.ell_bytes || c.list_chain || c.chain_jit) continue;
         const int64_t rows = int64_t(c.u32_b.size());
-        if (rows > 64 || c.a.idx < 0 || c.b.idx < 0) continue;
+        if (rows > 128 || c.a.idx < 0 || c.b.idx < 0) continue;
         const int64_t la = row_len(c.a), lb = row_len(c.b);
         // the covering copy right before it, into the same buffer?
         std::vector<uint32_t> init;

@@ -143,6 +143,7 @@ struct Step {
     };
     std::vector<FusedInput> fused_inputs;
     int fused_slab = 0, fused_out_base = 0, fused_zero_slot = 0;
+    int jit_persistent = 0;   // > 0: the specialised kernel loops over groups (persistent workgroups): this many are resident per CU
     int jit_items = 0;        // items per workgroup of the specialised kernel when it is not one per thread (the slab-in-LDS form: 64)
     int jit_threads = 256;    // workgroup size of the specialised kernel (64: one wave per workgroup, coalesced row I/O through LDS)
     int fused_jit_only = 0;   // the slab is too big for the LDS interpreter: runs only as the hiprtc-specialised kernel

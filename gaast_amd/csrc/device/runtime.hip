@@ -794,7 +794,8 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     if (plan.has_explog) args.push_back(&dom);
     const unsigned threads = unsigned(s.jit_threads);
     const unsigned per_block = unsigned(s.jit_items > 0 ? s.jit_items : s.jit_threads);   // (the slab-in-LDS form: 64 items per 512 threads)
-    const unsigned blocks = unsigned((batch + per_block - 1) / per_block);
+    unsigned blocks = unsigned((batch + per_block - 1) / per_block);
+    if (s.jit_persistent > 0) blocks = unsigned(std::min<int64_t>(blocks, int64_t(g_num_cu) * std::min(s.jit_persistent, 4)));   // persistent workgroups
     // (the argument block -- args, ptrs, strides and the locals they point at -- only has to live until this call returns:
     //  hipModuleLaunchKernel copies the kernel arguments into the dispatch packet's kernarg segment at call time)
     HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,

@@ -405,6 +405,7 @@ int main(int argc, char** argv) {
     single_list_tables_agree(8, GAAST_F64, dump_dir);
     single_list_tables_agree(8, GAAST_F32, dump_dir);
     single_list_tables_agree(9, GAAST_F64, dump_dir);
+    single_list_tables_agree(12, GAAST_F64, dump_dir);
     {
         const double euclid16[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         const double mixed9[9] = {1, 1, 1, 1, 1, 1, -1, -1, -1};

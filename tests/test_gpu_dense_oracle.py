@@ -692,3 +692,41 @@ def test_medium_programs_run_as_straight_line_code_over_slabs_in_lds(name, dtype
     assert np.array_equal(got.astype(np.float64), want)
     interp, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT)
     assert len(spec2.launches()) == 1 and spec2.launches()[0].startswith("ast_fused[") and np.array_equal(interp.astype(np.float64), want), spec2.launches()
+
+
+@pytest.mark.parametrize("n,dtype", [(8, ga.F64), (8, ga.F32), (9, ga.F64), (12, ga.F64)])
+def test_a_list_with_few_long_rows_runs_on_the_specialised_kernel_with_the_copy_folded_in(n, dtype):
+    """d = (a + b * c).g(2) (README.md:20-22, BASELINE configs[0]) beyond R^3: b * c projected on grade 2 is a list of C(n,2) rows
+    of 2^n terms -- too sparse for the dense kernels, too few rows for k_product_ell's thread per row.  Round 4: the list runs on
+    the specialised chain kernel alone (lane = (row, item)), the covering copy of a's grade 2 folded into its accumulators: ONE
+    launch.  With GAAST_FLAG_EXACT_ORDER bit for bit the oracle (f32: its F32 mode) and the plans without run-time compilation /
+    without fusion; by default long rows may be summed in slices (n = 12: 4,096-term rows): within 4 eps sum |terms|."""
+    full = full_grades(n)
+    build = lambda B: (B.input(0, full, n) + B.input(1, full, n) * B.input(2, full, n)).g(2)
+    batch = 77 if n < 12 else 5
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(120 + n)
+    rows = {s_: rows_of(n, full, batch, rng, npdt) for s_ in range(3)}
+    rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+    want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
+    got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_EXACT_ORDER)
+    assert mask == wmask == 0x4
+    assert len(spec.launches()) == 1 and "copy_grades_from" in spec.launches()[0] and "gaast_chain<" in spec.launches()[0] and "one list" in spec.launches()[0], spec.launches()
+    assert "re-ordered" not in spec.launches()[0]
+    assert np.array_equal(got.astype(np.float64), want)
+    two, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT | ga.FLAG_EXACT_ORDER)
+    assert len(spec2.launches()) == 2 and "copy_grades_from" in spec2.launches()[0] and "k_product_ell<" in spec2.launches()[1], spec2.launches()
+    assert np.array_equal(two.astype(np.float64), want)
+    # the unfused plan (one kernel per eval.rs arm, every operand materialised): zero fills, add_grades_from copies, the product
+    three, _, spec3 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_FUSION)
+    assert len(spec3.launches()) == 7 and sum("add_grades_from" in l for l in spec3.launches()) == 3, spec3.launches()
+    assert np.array_equal(three.astype(np.float64), want)
+    # default flags: tolerance mode (slices of long rows where lanes are free)
+    tol, tmask, spec4 = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+    assert tmask == wmask and len(spec4.launches()) == 1
+    eps = 2.0 ** -23 if dtype == ga.F32 else 2.0 ** -52
+    for i in range(batch):
+        S = abs_terms_bound(n, row_to_bits(n, full, rows64[1][i]), row_to_bits(n, full, rows64[2][i]))
+        bound = 4 * eps * (bits_to_row(n, [2], S) + np.abs(want[i])) + 1e-300
+        err = np.abs(tol[i].astype(np.float64) - want[i])
+        assert np.all(err <= bound), (i, float((err / bound).max()))
