@@ -29,7 +29,10 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_FP64_TFLOPS = 78.6     # datasheet (64 cycles per v_mfma_f64_16x16x4_f64 at 2.4 GHz); not in the local guide
 MEASURED_FP64_MFMA_TFLOPS = 74.3   # tools/microbench/mfma_f64_rate.hip on this pool (profiles/r03_microbench_mfma_f64_rate.txt)
 POWER_CAP_W, POWER_IDLE_W, POWER_W_PER_TFLOPS, POWER_W_PER_TBPS = 1400.0, 250.0, 7.2, 129.0   # measured, round 3 (DESIGN.md 4.1 "A power roofline")
-SIDE_CONFIGS = ("r8", "cl41", "r12d")   # the other single-GPU BASELINE configurations the default line also times
+# the other single-GPU BASELINE configurations the default line also times, then (round 4) one workload per kernel family added
+# this round: n = 6 on the matrix cores, the projected rotor sandwich (two lists, one launch), the versor inverse and
+# d = (a + b * c).g(2) beyond R^3 (whole-AST programs in one launch)
+SIDE_CONFIGS = ("r8", "cl41", "r12d", "gp6f32", "sand9g1", "vinv12", "cfg1_8")
 PEAK_HBM_GBPS = 8000.0     # spec; 6290 measured float4 copy
 GATHER_WATCHDOG_S = 240     # the multi-GPU gather legs give up after this long (the throughput line is printed regardless)
 GATHER_FAILED_EXIT = 3      # ... and the job then ends with this status: a hung or failed exchange is a FAILED run
@@ -137,6 +140,14 @@ def workload_spec(name):
                     label=f"rotor sandwich {'(R X ~R).g(1)' if g1 else 'R X ~R'} in {'R^{6,3}' if n == 9 else 'R^%d' % n}, R even ({half} components), X grade 1, f64"
                           + (", reference summation order" if m.group(3) else ""))
     # ---- whole-AST programs beyond a bare product or the sandwich (round 4; eval.rs has ten arms) ----
+    m = re.fullmatch(r"unary(\d+)", name)   # the element-wise arms on rows too big to fuse: GradedObj, Negation, Reverse, GradeInvolution, Addition, then a scaling product
+    if m:
+        from math import comb
+        n = int(m.group(1))
+        k = n // 2
+        return dict(n=n, metric=[1.0] * n, dtype=ga.F64, dtname="f64", inputs=[[k], [k], [0]],
+                    build=lambda a, b, s: (-(a.rev()) + b.ginvol()).rev() * s, entries=comb(n, k), default_batch=max(1024, min(1 << 20, (1 << 28) // (comb(n, k) * 8))),
+                    label=f"(-(a.rev()) + b.ginvol()).rev() * s in R^{n}: a, b grade {k} ({comb(n, k)} components), s scalar, f64 -- one kernel per eval.rs arm")
     m = re.fullmatch(r"(vinv|proj|cfg1_)(\d+)", name)
     if m:
         from math import comb
@@ -157,6 +168,15 @@ def workload_spec(name):
                     entries=comb(n, 2) << n, default_batch=max(1024, min(1 << 20, (1 << 29) // ((1 << n) * 8))),
                     read_len=comb(n, 2) + 2 * (1 << n),
                     label=f"d = (a + b * c).g(2) in R^{n}, full operands (README.md:20-22), f64")
+    m = re.fullmatch(r"gp(\d+)(f32|f64)(deg|gen)", name)   # the cold instantiations of the dense kernels: a null vector / a general diagonal metric
+    if m:
+        n, dt, var = int(m.group(1)), m.group(2), m.group(3)
+        full = list(range(n + 1))
+        sz = 4 if dt == "f32" else 8
+        metric = [0.0] + [1.0] * (n - 2) + [-1.0] if var == "deg" else [2.0 ** ((i % 5) - 2) * (-1.0 if i % 3 == 1 else 1.0) for i in range(n)]
+        return dict(n=n, metric=metric, dtype=ga.F32 if dt == "f32" else ga.F64, dtname=dt, inputs=[full, full],
+                    build=lambda a, b: a * b, entries=4 ** n, default_batch=max(64, min(1 << 22, (1 << 30) // ((1 << n) * sz))),
+                    label=f"R^{n} full MV x MV geometric product, {dt}, " + ("one null vector (PGA style), one -1" if var == "deg" else "general diagonal metric (rescaled basis)"))
     m = re.fullmatch(r"gp(\d+)(f32|f64)(s|x|ee|eo|oe|oo)?", name)   # e.g. gp10f32, gp10f32s (matrix representation), gp9f64x (exact order), gp12f32ee (even x even)
     if m:
         n, dt, var = int(m.group(1)), m.group(2), m.group(3)
@@ -396,7 +416,7 @@ def side_config(name, dev, stream, steps, warmup):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
-    in_len = sum(t.shape[1] for t in in_t if t.shape[0] == batch)
+    in_len = wl.get("read_len", sum(t.shape[1] for t in in_t if t.shape[0] == batch))
     res = {"workload": wl["label"], "key": name, "dim": n, "dtype": wl["dtname"], "batch": batch, "steps": steps, "warmup": warmup,
            "value": batch * steps / wall, "unit": "products/s" if len(wl["inputs"]) == 2 and wl["entries"] == 4 ** n else "evaluations/s",
            "ms_per_step": wall / steps * 1e3, "launches_per_eval": spec.launches(), "specialize_s": t_spec,

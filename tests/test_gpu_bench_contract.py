@@ -76,19 +76,24 @@ def test_a_failed_gather_ends_the_job_non_zero(tmp_path):
 
 def test_default_line_carries_the_other_single_gpu_configs():
     """The DEFAULT run (no --workload, no --batch) also times BASELINE configs[1] (R^8 f32), configs[4] (R^{4,1} sandwich,
-    f64) and R^12 in f64, each with its own roofline object, so that they stop resting on builder-run profiles."""
+    f64) and R^12 in f64, each with its own roofline object, so that they stop resting on builder-run profiles -- and, since
+    round 4, one workload per kernel family added that round (n = 6 on the matrix cores, the projected sandwich as one launch of
+    two lists, the versor inverse and d = (a + b * c).g(2) beyond R^3 as one launch each)."""
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                           "--no-alt", "--no-latency"], capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert run.returncode == 0, run.stderr[-2000:]
     d = json.loads([l for l in run.stdout.splitlines() if l.strip()][0])
     assert d["config"]["batch_per_gpu"] == 65536 and d["roofline"]["kernel"].endswith(":: k_gp_mfma32p<false,12>")
     side = {c["key"]: c for c in d["configs"]}
-    assert set(side) == {"r8", "cl41", "r12d"}
-    for key, bound, kern in (("r8", "mfma", "k_gp_mfma16x4<float,false,8,"), ("cl41", "hbm", "ast_jit"), ("r12d", "mfma", "k_gp_mfma16x4<double,false,12,")):
+    assert set(side) == {"r8", "cl41", "r12d", "gp6f32", "sand9g1", "vinv12", "cfg1_8"}
+    for key, bound, kern in (("r8", "mfma", "k_gp_mfma16x4<float,false,8,"), ("cl41", "hbm", "ast_jit"), ("r12d", "mfma", "k_gp_mfma16x4<double,false,12,"),
+                             ("gp6f32", "hbm", "k_gp_mfma6<float,"), ("sand9g1", "hbm", "gaast_chain<double>"), ("vinv12", "hbm", "k_reduce_scale<double>"),
+                             ("cfg1_8", "hbm", "gaast_chain<double>[one list")):
         c = side[key]
         assert "error" not in c, c
         r = c["roofline"]
-        assert r["bound"] == bound and kern in r["kernel"] and 0.3 < r["frac"] < 1.0 and c["value"] > 0
+        assert r["bound"] == bound and kern in r["kernel"] and 0.1 < r["frac"] < 1.0 and c["value"] > 0
+        assert len(c["launches_per_eval"]) == 1 if key in ("sand9g1", "vinv12", "cfg1_8") else True
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
 
 
