@@ -337,6 +337,96 @@ __global__ __launch_bounds__(256) void k_reduce_scale(ReduceScaleArgs<T> p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_elementwise: a RUN of element-wise arms on one buffer -- GradedObj copies / additions (eval.rs:45-50 -> graded.rs:67-78), the
+// sign arms Negation / Reverse / GradeInvolution (eval.rs:55-60, 87-102 -> graded.rs:61-65) -- and, optionally, the product of
+// one-term rows that scales the result by a scalar operand (eval.rs:61-86) as ONE pass: every component executes its own
+// statements in the program's order (they never look at another component), so the result is bit for bit what one launch per arm
+// produces -- k_axpy_map, k_flip, k_flip, ... each a full read-modify-write of the buffer (an expression like
+// (-(a.rev()) + b.ginvol()).rev() * s at n = 12: six passes over 268 MB instead of one).
+//   ops: [n_ops][n_comp] words, statement k of component c:  [1:0] 0 nothing, 1 v = v + src, 2 v = -v, 3 v = 0.0 + src;
+//        [4:2] source slot;  [31:16] source offset.   Epilogue (scale): out[out_off[c]] = 0.0 + ((0.0 + v) * s) * coeff[c].
+// ------------------------------------------------------------------------------------------
+constexpr int ELEMENTWISE_MAX_SRC = 6;
+template <typename T>
+struct ElementwiseArgs {
+    T* res;
+    int64_t res_stride;
+    const T* src[ELEMENTWISE_MAX_SRC];
+    int64_t src_stride[ELEMENTWISE_MAX_SRC];
+    const uint32_t* ops;        // [n_ops][n_comp]
+    const uint32_t* comp_off;   // offset of component c in the res row (the run's own buffer; unused when it is folded away)
+    int n_ops, n_comp;
+    int load_first;             // 1: v starts from the buffer's current value (the run does not begin with a covering copy)
+    // epilogue: multiply by a scalar operand and store somewhere else (the run's buffer is then never written)
+    T* out;
+    int64_t out_stride;
+    const uint32_t* out_off;    // per component, or NULL: no epilogue
+    const T* coeff;
+    const T* scalar;
+    int64_t scalar_stride;
+    int scalar_off, canon_v, canon_s, s_is_left;
+    int64_t batch;
+};
+
+constexpr int ELEMENTWISE_MAX_OPS = 8;      // statements per component of one pass (longer runs are cut by the plan builder)
+// A thread keeps ONE component and walks the items (blockIdx.y strides over them), FOUR items per step: its statement words,
+// offsets and coefficient are decoded once, and per step the operand loads of four items are all in flight before the first
+// statement runs (per (item, component) threads re-read the tables for every element: 0.27 of the HBM roof; one item per
+// step with its loads behind the previous item's store: 0.20).  Consecutive threads hold consecutive components: coalesced rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_elementwise(ElementwiseArgs<T> p) {
+    constexpr int U = 4;
+    const int c = int(blockIdx.x) * 256 + int(threadIdx.x);
+    if (c >= p.n_comp) return;
+    const T zero = T(0);
+    uint32_t op[ELEMENTWISE_MAX_OPS];
+    const T* ld_ptr[ELEMENTWISE_MAX_OPS];
+    int64_t ld_stride[ELEMENTWISE_MAX_OPS];
+#pragma unroll
+    for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) {
+        const uint32_t w = k < p.n_ops ? p.ops[size_t(k) * p.n_comp + c] : 0u;
+        op[k] = w & 3u;
+        const int sl = int((w >> 2) & 7u);
+        ld_ptr[k] = p.src[sl] + (w >> 16);      // (only dereferenced when the statement reads a source)
+        ld_stride[k] = p.src_stride[sl];
+    }
+    const uint32_t own = p.out_off ? 0u : p.comp_off[c];
+    const uint32_t oo = p.out_off ? p.out_off[c] : 0u;
+    const T cf = p.out_off ? p.coeff[c] : zero;
+    for (int64_t item0 = int64_t(blockIdx.y) * U; item0 < p.batch; item0 += int64_t(gridDim.y) * U) {
+        T x[U][ELEMENTWISE_MAX_OPS], v[U], s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t item = item0 + u < p.batch ? item0 + u : item0;   // (the tail re-reads the step's first item; it is not stored twice)
+#pragma unroll
+            for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) x[u][k] = (op[k] & 1u) ? ld_ptr[k][item * ld_stride[k]] : zero;   // ops 1 and 3 read
+            v[u] = p.load_first ? p.res[item * p.res_stride + own] : zero;
+            s[u] = p.out_off ? p.scalar[item * p.scalar_stride + p.scalar_off] : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (item0 + u >= p.batch) break;
+            T val = v[u];
+#pragma unroll
+            for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) {
+                if (op[k] == 2u) val = -val;                                       // graded.rs:63
+                else if (op[k]) val = (op[k] == 3u ? zero : val) + x[u][k];       // graded.rs:74 (op 3: onto the fresh +0.0 of init_null_mv)
+            }
+            const int64_t item = item0 + u;
+            if (p.out_off) {
+                T sc = s[u];
+                if (p.canon_s) sc = zero + sc;
+                if (p.canon_v) val = zero + val;
+                const T pr = p.s_is_left ? sc * val : val * sc;
+                p.out[item * p.out_stride + oo] = zero + pr * cf;         // the fresh result buffer: 0.0 + (l * r) * coeff
+            } else {
+                p.res[item * p.res_stride + own] = val;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_product_ell: the exact product for lists whose rows (result components) all have the same
 // number of entries and whose coefficients are +-1 -- every dense product of a non-degenerate
 // algebra.  Same terms in the same (reference) order with the same three roundings per term as

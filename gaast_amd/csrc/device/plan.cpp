@@ -2531,6 +2531,145 @@ static void chain_list_into_list(Plan& plan) {
     plan.steps = std::move(kept);
 }
 
+// A RUN of element-wise arms on one buffer -- add_grades_from copies / additions of bound inputs, Negation / Reverse / GradeInvolution
+// sign flips (eval.rs:45-60, 87-102) -- costs one full read-modify-write of the buffer PER ARM when every arm is a launch
+// ((-(a.rev()) + b.ginvol()).rev() * s at n = 12: six passes).  The components never look at each other, so the run becomes ONE
+// k_elementwise pass in which each component executes its own statements in program order: bit-identical.  When the run's buffer is
+// only the operand of a product of one-term rows with a scalar operand, that product rides along as the pass's epilogue and the
+// buffer is never written at all.
+static void fuse_elementwise_runs(Plan& plan) {
+    if (plan.flags & (GAAST_FLAG_NO_FUSION | GAAST_FLAG_DEBUG_NO_CHAIN)) return;
+    auto same = [](BufRef x, BufRef y) { return x.kind == y.kind && x.idx == y.idx; };
+    auto row_len = [&](BufRef r) -> int64_t {
+        return r.kind == BufKind::NODE ? plan.node_buffers[size_t(r.idx)].row_len : r.kind == BufKind::INPUT ? plan.input_layouts[size_t(r.idx)].row_len
+                                                                                                           : plan.out_layout.row_len;
+    };
+    for (size_t i = 0; i < plan.steps.size(); ++i) {
+        const Step& first = plan.steps[i];
+        if (first.kind != Step::AXPY && first.kind != Step::FLIP) continue;
+        const BufRef R = first.res;
+        size_t j = i;
+        std::vector<BufRef> srcs;
+        bool ok = true;
+        while (j < plan.steps.size() && ok) {
+            const Step& t = plan.steps[j];
+            if ((t.kind != Step::AXPY && t.kind != Step::FLIP) || !same(t.res, R)) break;
+            if (t.kind == Step::AXPY) {
+                if (t.a.kind != BufKind::INPUT) break;
+                bool known = false;
+                for (const BufRef& b : srcs) known = known || same(b, t.a);
+                if (!known) {
+                    if (srcs.size() == 6) break;
+                    srcs.push_back(t.a);
+                }
+            }
+            ++j;
+            if (j - i == 8) break;   // (a pass holds eight statements per component; a longer run continues in a second pass)
+        }
+        const size_t n_ops = j - i;
+        if (n_ops < 2) continue;
+        // components the run touches, in row order
+        const int64_t rl = row_len(R);
+        std::vector<int32_t> comp_of(size_t(rl), -1);
+        std::vector<uint32_t> comps;
+        for (size_t k = i; k < j; ++k)
+            for (uint32_t w : plan.steps[k].u32_a) {
+                const uint32_t off = plan.steps[k].kind == Step::AXPY ? (w & 0xffffu) : w;
+                if (comp_of[off] < 0) comp_of[off] = 0;
+            }
+        for (int64_t o = 0; o < rl; ++o)
+            if (comp_of[size_t(o)] == 0) {
+                comp_of[size_t(o)] = int32_t(comps.size());
+                comps.push_back(uint32_t(o));
+            }
+        const size_t nc = comps.size();
+        if (nc == 0) continue;
+        std::vector<uint32_t> ops(n_ops * nc, 0u);
+        for (size_t k = i; k < j; ++k) {
+            const Step& t = plan.steps[k];
+            if (t.kind == Step::FLIP) {
+                for (uint32_t off : t.u32_a) ops[(k - i) * nc + size_t(comp_of[off])] = 2u;
+            } else {
+                uint32_t slot = 0;
+                for (size_t q = 0; q < srcs.size(); ++q)
+                    if (same(srcs[q], t.a)) slot = uint32_t(q);
+                for (uint32_t w : t.u32_a) ops[(k - i) * nc + size_t(comp_of[w & 0xffffu])] = (t.beta ? 1u : 3u) | (slot << 2) | ((w >> 16) << 16);
+            }
+        }
+        // does every component start with a copy (the run then never reads its buffer)?
+        bool load_first = false;
+        for (size_t c = 0; c < nc && !load_first; ++c) {
+            size_t k = 0;
+            while (k < n_ops && ops[k * nc + c] == 0u) ++k;
+            load_first = k == n_ops || (ops[k * nc + c] & 3u) != 3u;
+        }
+        Step f;
+        f.kind = Step::ELEMENTWISE;
+        f.res = R;
+        f.ew_src = srcs;
+        f.ew_ops = int(n_ops);
+        f.ew_load_first = load_first ? 1 : 0;
+        f.u32_a = std::move(ops);
+        f.u32_b = comps;
+        f.name = "elementwise[" + std::to_string(n_ops) + " arms:";
+        for (size_t k = i; k < j; ++k) f.name += " " + plan.steps[k].name.substr(0, plan.steps[k].name.find('[') == std::string::npos ? 8 : plan.steps[k].name.find('['));
+        f.name += "]";
+        // the scaling product right after the run, reading the run's buffer and a scalar?
+        size_t drop_to = j;
+        if (R.kind == BufKind::NODE && j < plan.steps.size() && !load_first && int64_t(nc) == rl) {
+            const Step& p2 = plan.steps[j];
+            const bool r_left = p2.kind == Step::PRODUCT_CSR && same(p2.a, R), r_right = p2.kind == Step::PRODUCT_CSR && same(p2.b, R);
+            if (p2.kind == Step::PRODUCT_CSR && p2.beta == 0 && r_left != r_right && !p2.list_chain && !p2.chained && p2.u32_b.size() == nc) {
+                const BufRef S = r_left ? p2.b : p2.a;
+                bool fits = row_len(S) == 1 && !same(S, R) && !same(p2.res, R);
+                for (size_t r = 0; r + 1 < p2.u32_a.size() && fits; ++r) fits = p2.u32_a[r + 1] - p2.u32_a[r] == 1;
+                for (size_t k = 0; k < plan.steps.size() && fits; ++k) {   // nobody else reads the run's buffer
+                    if (k >= i && k <= j) continue;
+                    const Step& t = plan.steps[k];
+                    if (same(t.res, R) || (t.a.idx >= 0 && same(t.a, R)) || (t.b.idx >= 0 && same(t.b, R))) fits = false;
+                    if ((t.chained || t.list_chain) && (same(t.pre_a, R) || same(t.pre_b, R))) fits = false;
+                }
+                std::vector<uint32_t> out_off(nc, 0u);
+                std::vector<double> coeff(nc, 0.0);
+                std::vector<char> seen(nc, 0);
+                for (size_t r = 0; r + 1 < p2.u32_a.size() && fits; ++r) {
+                    const uint32_t e = p2.u32_c[p2.u32_a[r]];
+                    const uint32_t roff = r_left ? (e & 0xffffu) : (e >> 16);
+                    fits = roff < uint32_t(rl) && comp_of[roff] >= 0 && !seen[size_t(comp_of[roff])];
+                    if (!fits) break;
+                    seen[size_t(comp_of[roff])] = 1;
+                    out_off[size_t(comp_of[roff])] = p2.u32_b[r];
+                    coeff[size_t(comp_of[roff])] = p2.coeff[p2.u32_a[r]];
+                }
+                if (fits) {
+                    f.ew_scale = 1;
+                    f.res = p2.res;
+                    f.b = S;
+                    f.u32_c = std::move(out_off);
+                    f.coeff = std::move(coeff);
+                    f.ew_scalar_off = 0;
+                    f.ew_canon_v = r_left ? p2.canon_a : p2.canon_b;
+                    f.ew_canon_s = r_left ? p2.canon_b : p2.canon_a;
+                    f.ew_s_is_left = r_left ? 0 : 1;
+                    f.beta = 0;
+                    f.n_entries = p2.n_entries;
+                    f.name += " * scalar -> " + p2.name;
+                    if (plan.node_dead.size() != plan.node_buffers.size()) plan.node_dead.assign(plan.node_buffers.size(), 0);
+                    plan.node_dead[size_t(R.idx)] = 1;
+                    drop_to = j + 1;
+                }
+            }
+        }
+        std::vector<Step> kept;
+        for (size_t k = 0; k < plan.steps.size(); ++k) {
+            if (k == i) kept.push_back(std::move(f));
+            else if (k > i && k < drop_to) continue;
+            else kept.push_back(std::move(plan.steps[k]));
+        }
+        plan.steps = std::move(kept);
+    }
+}
+
 // x (*) f(<l, r>): a product into ONE scalar component (a single row: norm_sq), an optional ScalarUnaryOp on it, and a product of
 // one-term rows that multiplies another row by that scalar -- a.rev() * a.norm_sq().sinv(), the versor inverse of expr.rs:363-371,
 // where the rows no longer fit a fused slab -- become ONE k_reduce_scale launch (kernels_exact.hip.hpp): reference order and
@@ -2720,6 +2859,7 @@ void build_plan(const gaast_program_desc& desc, Plan& plan) {
         }
     }
     if (!try_fuse(plan)) {
+        fuse_elementwise_runs(plan);
         fuse_reduce_scale(plan);
         chain_sparse_into_dense(plan);
         uniform_csr_to_ell(plan);

@@ -35,7 +35,7 @@ inline Layout make_layout(int dim, uint64_t mask) {
 }
 
 struct Step {
-    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG, REDUCE_SCALE } kind = ZERO;
+    enum Kind { ZERO, AXPY, FLIP, SUNARY, PRODUCT_CSR, PRODUCT_DENSE, FUSED, EXPLOG, REDUCE_SCALE, ELEMENTWISE } kind = ZERO;
     BufRef res, a, b;
     std::string name;
     std::string hip_kernel;        // the HIP kernel (template and arguments) prepare_step picked: appended to the launch label
@@ -128,6 +128,12 @@ struct Step {
     // a.rev() * a.norm_sq().sinv() and normalisations, where the rows no longer fit a fused slab (n >= 9) -- in ONE launch, one wave per
     // item: u32_a / coeff = the reduction's terms in the reference's order (left | right << 16, coefficient), a / b = its operands;
     // u32_b / coeff_b = the scaling's rows (operand offset | result offset << 16, coefficient), pre_a = its row operand.
+    // ELEMENTWISE (plan.cpp: fuse_elementwise_runs): a run of AXPY / FLIP steps on one buffer (and, when that buffer is only the operand
+    // of a product of one-term rows with a scalar, that product too) in one pass: u32_a = [n_ops][n_comp] statement words, u32_b = the
+    // components' offsets in the run's buffer, ew_src = the source buffers; with the scaling epilogue: u32_c = result offsets, coeff =
+    // coefficients, b = the scalar operand (1-component row), res = the product's result.
+    std::vector<BufRef> ew_src;
+    int ew_ops = 0, ew_load_first = 0, ew_scale = 0, ew_scalar_off = 0, ew_canon_v = 0, ew_canon_s = 0, ew_s_is_left = 0;
     int rs_op = 0;                       // 0: none, 1: 1 / s, 2: sqrt(s)  (eval.rs:103-110)
     int rs_canon_s = 0;                  // the scalar is re-read as a product operand: 0.0 + s
     int use_mfma6 = 0;   // k_gp_mfma6<T> (n = 6: four 16x16x4 instructions per item, the two top vectors split over the tile's rows and columns)

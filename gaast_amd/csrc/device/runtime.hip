@@ -417,6 +417,12 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         // persistent workgroups: as many as are resident at once (register- and LDS-limited)
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
     }
+    case Step::ELEMENTWISE:
+        s.hip_kernel = "k_elementwise<" + tn + ">";
+        return GAAST_OK;
+    case Step::AXPY: s.hip_kernel = "k_axpy_map<" + tn + ">"; return GAAST_OK;
+    case Step::FLIP: s.hip_kernel = "k_flip<" + tn + ">"; return GAAST_OK;
+    case Step::SUNARY: s.hip_kernel = "k_scalar_unary<" + tn + ">"; return GAAST_OK;
     case Step::REDUCE_SCALE: {
         s.threads = 256;
         s.kern[0] = reinterpret_cast<const void*>(&k_reduce_scale<T>);
@@ -836,6 +842,48 @@ int run_fused(const Step& s, const Plan& plan, const std::vector<Bound>& in_boun
     return GAAST_OK;
 }
 
+// a run of element-wise arms (and the scaling product after it) in one pass: plan.cpp: fuse_elementwise_runs
+template <typename T, typename Resolve>
+int run_elementwise(const Step& s, const Bound& res, Resolve&& resolve, int64_t batch) {
+    ElementwiseArgs<T> q;
+    std::memset(&q, 0, sizeof(q));
+    Layout unused;
+    for (size_t i = 0; i < s.ew_src.size() && i < size_t(ELEMENTWISE_MAX_SRC); ++i) {
+        const Bound b = resolve(s.ew_src[i], &unused);
+        q.src[i] = static_cast<const T*>(b.ptr);
+        q.src_stride[i] = b.stride;
+    }
+    q.ops = static_cast<const uint32_t*>(s.d_a);
+    q.comp_off = static_cast<const uint32_t*>(s.d_b);
+    q.n_ops = s.ew_ops;
+    q.n_comp = int(s.u32_b.size());
+    q.load_first = s.ew_load_first;
+    q.batch = batch;
+    if (s.ew_scale) {
+        const Bound sc = resolve(s.b, &unused);
+        q.out = static_cast<T*>(res.ptr);
+        q.out_stride = res.stride;
+        q.out_off = static_cast<const uint32_t*>(s.d_c);
+        q.coeff = static_cast<const T*>(s.d_coeff);
+        q.scalar = static_cast<const T*>(sc.ptr);
+        q.scalar_stride = sc.stride;
+        q.scalar_off = s.ew_scalar_off;
+        q.canon_v = s.ew_canon_v;
+        q.canon_s = s.ew_canon_s;
+        q.s_is_left = s.ew_s_is_left;
+    } else {
+        q.res = static_cast<T*>(res.ptr);
+        q.res_stride = res.stride;
+    }
+    // x: the components (a thread keeps one), y: strides over the items -- enough workgroups to fill the chip a few times over
+    const unsigned gx = unsigned((q.n_comp + 255) / 256);
+    const int64_t want_y = std::max<int64_t>(1, int64_t(g_num_cu) * 16 / gx);
+    const unsigned gy = unsigned(std::min<int64_t>(std::min<int64_t>((batch + 3) / 4, want_y), 65535));   // (a thread takes four items per step)
+    hipLaunchKernelGGL(k_elementwise<T>, dim3(gx, gy), dim3(256), 0, g_stream, q);
+    HIP_TRY(hipGetLastError());
+    return GAAST_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1035,7 +1083,10 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             if (int st = upload_t(s.pre_coeff, &s.d_pre_coeff)) return st;
             if (int st = upload_t(s.pre_row_scale, &s.d_pre_row_scale)) return st;
         }
-        if (s.kind == Step::REDUCE_SCALE) {
+        if (s.kind == Step::ELEMENTWISE) {
+            for (const BufRef& b : s.ew_src)
+                if (b.kind == BufKind::INPUT) plan.slot_used[size_t(b.idx)] = 1;
+        } else if (s.kind == Step::REDUCE_SCALE) {
             if (s.pre_a.idx >= 0 && s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
         } else if (s.list_chain || s.list_jit) {
             if (s.pre_a.idx >= 0 && s.pre_a.kind == BufKind::INPUT) plan.slot_used[size_t(s.pre_a.idx)] = 1;
@@ -1340,6 +1391,11 @@ int eval_range(gaast_hip_program_t prog, const std::vector<Bound>& in_bound0, ga
         if (s.kind == Step::FUSED) {
             const int st = plan.dtype == GAAST_F32 ? run_fused<float>(s, plan, in_bound, res, count)
                                                    : run_fused<double>(s, plan, in_bound, res, count);
+            if (st != GAAST_OK) return st;
+            continue;
+        }
+        if (s.kind == Step::ELEMENTWISE) {
+            const int st = plan.dtype == GAAST_F32 ? run_elementwise<float>(s, res, resolve, count) : run_elementwise<double>(s, res, resolve, count);
             if (st != GAAST_OK) return st;
             continue;
         }

@@ -730,3 +730,37 @@ def test_a_list_with_few_long_rows_runs_on_the_specialised_kernel_with_the_copy_
         bound = 4 * eps * (bits_to_row(n, [2], S) + np.abs(want[i])) + 1e-300
         err = np.abs(tol[i].astype(np.float64) - want[i])
         assert np.all(err <= bound), (i, float((err / bound).max()))
+
+
+@pytest.mark.parametrize("dtype", [ga.F64, ga.F32])
+@pytest.mark.parametrize("shape", ["scaled", "plain", "mixed_grades"])
+def test_runs_of_element_wise_arms_are_one_pass(shape, dtype):
+    """GradedObj, Negation, Reverse, GradeInvolution, Addition (eval.rs:45-60, 87-102) on rows too big for a fused slab: round 3 ran
+    one launch per arm (k_axpy_map, k_flip, ... each a full read-modify-write of the buffer).  Round 4: the run is ONE k_elementwise
+    pass, every component executing its own statements in program order -- with the product that scales the result by a scalar
+    operand as its epilogue when there is one.  Bit for bit the oracle (f32: its F32 mode) and the one-launch-per-arm plan;
+    Q1 of SURVEY section 7 included (the unary arms act on the whole accumulator)."""
+    n, batch = 12, 23
+    npdt = np.float32 if dtype == ga.F32 else np.float64
+    rng = np.random.default_rng(5150)
+    if shape == "scaled":
+        build = lambda B: (-(B.input(0, [6], n).rev()) + B.input(1, [6], n).ginvol()).rev() * B.input(2, [0], n)
+        rows = {0: rows_of(n, [6], batch, rng, npdt), 1: rows_of(n, [6], batch, rng, npdt), 2: rows_of(n, [0], batch, rng, npdt)}
+        expect = 1
+    elif shape == "plain":
+        build = lambda B: -((B.input(0, [5], n) + B.input(1, [5], n).rev()).ginvol() + B.input(0, [5], n))
+        rows = {0: rows_of(n, [5], batch, rng, npdt), 1: rows_of(n, [5], batch, rng, npdt)}
+        expect = 1
+    else:   # operands with several grades each: flips that touch only some of the components (grade 5, 6, 7: Reverse negates 6 and 7)
+        build = lambda B: (B.input(0, [5, 6, 7], n).rev() - B.input(1, [5, 6, 7], n)).ginvol()
+        rows = {0: rows_of(n, [5, 6, 7], batch, rng, npdt), 1: rows_of(n, [5, 6, 7], batch, rng, npdt)}
+        expect = 1
+    rows64 = {s_: r.astype(np.float64) for s_, r in rows.items()}
+    want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
+    got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
+    assert mask == wmask
+    assert len(spec.launches()) == expect and spec.launches()[0].startswith("elementwise[") and "k_elementwise<" in spec.launches()[0], spec.launches()
+    assert np.array_equal(got.view(np.uint32 if dtype == ga.F32 else np.uint64), want.astype(npdt).view(np.uint32 if dtype == ga.F32 else np.uint64))   # signs of zeros too
+    per_arm, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
+    assert len(spec2.launches()) > 2 and any("k_flip<" in l for l in spec2.launches()) and any("k_axpy_map<" in l for l in spec2.launches()), spec2.launches()
+    assert np.array_equal(per_arm.view(np.uint32 if dtype == ga.F32 else np.uint64), got.view(np.uint32 if dtype == ga.F32 else np.uint64))

@@ -16,7 +16,11 @@ sys.path.insert(0, ROOT)
 HIP_KERNEL = {"r12": "k_gp_mfma32p", "r8": "k_gp_mfma16x4<float>", "cl41": "gaast_jit", "cl41g1": "gaast_jit", "r12s": "k_gp_spinor12s",
               "r12d": "k_gp_mfma16x4<double>", "r8d": "k_gp_mfma16x4<double>", "sand9": "k_gp_mfma16x4<double,...,8,0,false,true> (chained)",
               "sand10": "k_gp_mfma16x4<double,...,9,0,false,true> (chained)", "gp12f32ee": "k_gp_mfma32p<false,11>",
-              "gp7f32": "k_gp_mfma7<float>", "sand8": "k_gp_mfma7<double,...,false,true> (chained)", "sand9g1": "k_product_ell_chain<double>"}
+              "gp7f32": "k_gp_mfma7<float>", "sand8": "k_gp_mfma7<double,...,false,true> (chained)", "sand9g1": "gaast_chain (hiprtc)",
+              "sand9g1x": "gaast_chain (hiprtc), reference order", "sand8g1": "gaast_chain (hiprtc)", "sand10g1": "gaast_chain (hiprtc)",
+              "gp6f32": "k_gp_mfma6<float,false,true>", "gp6f64": "k_gp_mfma6<double,false,true>", "cl41s": "gaast_jit",
+              "vinv8": "gaast_jit (slabs in LDS)", "proj12": "gaast_jit (slabs in LDS)", "vinv12": "k_reduce_scale<double>",
+              "cfg1_8": "gaast_chain (hiprtc), one list", "cfg1_12": "gaast_chain (hiprtc), one list", "unary12": "k_elementwise<double>"}
 
 
 def main():

@@ -53,6 +53,12 @@ int main(int argc, char** argv) {
             gaast_expr_t e = gaast_expr_product(gaast_expr_product(v, bv, GAAST_PROD_INNER), gaast_expr_vinv(bv), GAAST_PROD_INNER);
             dump("proj", e, n, GAAST_F64, flags);
         }
+        {   // element-wise arms on rows too big to fuse, then a scaling product
+            const int k = n / 2;
+            gaast_expr_t a = gaast_expr_input(0, uint64_t(1) << k, n), b = gaast_expr_input(1, uint64_t(1) << k, n), sc = gaast_expr_input(2, 1, n);
+            gaast_expr_t e = gaast_expr_product(gaast_expr_rev(gaast_expr_add(gaast_expr_neg(gaast_expr_rev(a)), gaast_expr_ginvol(b))), sc, GAAST_PROD_GEOMETRIC);
+            dump("unary", e, n, GAAST_F64, flags);
+        }
         {   // README.md:20-22: d = (a + b * c).g(2), full operands
             gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n), c = gaast_expr_input(2, full_mask(n), n);
             gaast_expr_t e = gaast_expr_g(gaast_expr_add(a, gaast_expr_product(b, c, GAAST_PROD_GEOMETRIC)), 2);
