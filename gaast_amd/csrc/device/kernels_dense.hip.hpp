@@ -1252,45 +1252,72 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
         if (int64_t(blockIdx.x) < p.batch) fetch(blockIdx.x);
     }
 
-    // CHAINED, register-prefetch path: when the list is R X of the sandwich -- four rows of (n padded to) 12 terms per thread, +-1
-    // coefficients: sand9 (this kernel at n = 8) -- a thread keeps the words of its rows and the rows' image words in registers for all its items
-    // (list_eval_rows re-reads them from L1 per item: 52 vector-memory instructions per item and wave).  The words stay PACKED in
-    // their registers (each is made opaque inside the item loop: hoisted, their decoded halves would triple the registers and
-    // spill).  Same terms, same order, same four-term grouping: the same bits.
-    constexpr bool LIST_CACHE = CHAINED && FAST && NDIM == 8;   // (n = 9: the 52 registers spill)
-    const bool list_cached = LIST_CACHE && p.pre_width == 12 && p.pre_rows == 4 * THREADS && p.pre_row_scale == nullptr;
-    uint32_t ce[LIST_CACHE ? 4 : 1][LIST_CACHE ? 12 : 1], crow[4] = {0, 0, 0, 0};
+    // CHAINED, register-prefetch path, the list is R X of a sandwich (four rows per thread, one term per basis vector, +-1
+    // coefficients, padded to 12 by the host): the thread keeps what its rows need in registers for all its items
+    // (list_eval_rows re-reads the words from L1 and decodes them per item: ~9.5 vector instructions per term, and vector
+    // instructions do NOT issue beside the matrix ones on this chip -- tools/microbench/coissue*.hip, inwave.hip; round 3's
+    // sand9 spent 460 of its 561 vector instructions per item here).  Kept per term: the LDS byte address of both operands;
+    // the term's sign is an address too -- X sits in the scratch twice, +X and -X, and l * (-x) has the bits of (l * x) * (-1.0)
+    // (eval.rs:82).  So a term is two reads, one multiplication, one addition, in the list's order: the same bits.
+    //   NDIM == 8 (sand9): 2 x 36 plain addresses (228 registers with the unrolled matrix loop's);
+    //   NDIM == 9 (sand10, two waves per item): both addresses in one register (l | r << 16), two more instructions per term
+    // -- 80 registers more would spill.
+    constexpr bool LIST_CACHE = CHAINED && FAST && (NDIM == 8 || NDIM == 9);
+    constexpr bool LC_PACKED = NDIM != 8;
+    constexpr int LW = NDIM + 1;                  // terms per row of R X in n = NDIM + 1 dimensions
+    bool list_cached = LIST_CACHE && same_src && p.pre_width == 12 && p.pre_rows == 4 * THREADS && p.pre_row_scale == nullptr;
+    uint32_t ce[(LIST_CACHE && LC_PACKED) ? 4 : 1][(LIST_CACHE && LC_PACKED) ? LW : 1];
+    // (pointers, not offsets: the LDS base is a link-time constant the compiler adds per use otherwise)
+    const lds_t *cl[(LIST_CACHE && !LC_PACKED) ? 4 : 1][(LIST_CACHE && !LC_PACKED) ? LW : 1], *cr[(LIST_CACHE && !LC_PACKED) ? 4 : 1][(LIST_CACHE && !LC_PACKED) ? LW : 1];
+    uint32_t crow[4] = {0, 0, 0, 0};
     if constexpr (LIST_CACHE) {
         if (list_cached) {
+            const uint32_t ll = uint32_t(p.pre_left_len), rl = uint32_t(p.pre_right_len);
+            bool pads_only = true;   // beyond LW terms: the host's padding entries in every row
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 crow[rr] = p.pre_row_map[tid + rr * THREADS];
 #pragma unroll
-                for (int t = 0; t < 12; ++t) ce[rr][t] = p.pre_entries[t * (4 * THREADS) + tid + rr * THREADS];
+                for (int t = 0; t < 12; ++t) {
+                    const uint32_t e = p.pre_entries[t * (4 * THREADS) + tid + rr * THREADS];
+                    if (t < LW) {
+                        const uint32_t la = (uint32_t(p.pre_scratch) + (e & 0x7fffu)) << ES;
+                        const uint32_t ra = (uint32_t(p.pre_scratch) + ll + ((e >> 16) & 0x7fffu) + ((e >> 31) ? rl + 1u : 0u)) << ES;
+                        if constexpr (LC_PACKED) {
+                            ce[rr][t < LW ? t : 0] = la | (ra << 16);
+                        } else {
+                            cl[rr][t < LW ? t : 0] = (const lds_t*)(lds + la);
+                            cr[rr][t < LW ? t : 0] = (const lds_t*)(lds + ra);
+                        }
+                    } else {
+                        pads_only = pads_only && (e & 0x7fffu) == ll + rl;
+                    }
+                }
             }
+            // (every LDS byte address of this kernel is below 2^16: the packed form loses nothing)
+            list_cached = __all(pads_only) != 0;
         }
     }
     auto cached_list = [&]() {
         if constexpr (LIST_CACHE) {
-            const char* l = reinterpret_cast<const char*>(smem + p.pre_scratch);
-            const char* r = l + size_t(p.pre_left_len) * sizeof(T);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                T acc = T(0);
+                T lv[LW], rv[LW];
 #pragma unroll
-                for (int k0 = 0; k0 < 12; k0 += 4) {
-                    T prod[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        uint32_t e = ce[rr][k0 + t];
-                        asm volatile("" : "+v"(e));
-                        prod[t] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
-                                                   *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
-                                               e & 0x80000000u);
+                for (int t = 0; t < LW; ++t) {
+                    if constexpr (LC_PACKED) {
+                        uint32_t e = ce[rr][t];
+                        asm volatile("" : "+v"(e));   // the word stays packed in its register
+                        lv[t] = *(const lds_t*)(lds + (e & 0xffffu));
+                        rv[t] = *(const lds_t*)(lds + (e >> 16));
+                    } else {
+                        lv[t] = *cl[rr][t];
+                        rv[t] = *cr[rr][t];
                     }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc = acc + prod[t];
                 }
+                T acc = T(0);                                      // the fresh cache buffer of eval.rs:21-33
+#pragma unroll
+                for (int t = 0; t < LW; ++t) acc = acc + lv[t] * rv[t];
                 uint32_t w = crow[rr];
                 asm volatile("" : "+v"(w));
                 const uint32_t pos = (w >> 16) & 0x7fffu;
@@ -1323,7 +1350,11 @@ __global__ __launch_bounds__(64 << (NDIM - 8)) __attribute__((amdgpu_waves_per_e
             }
             if constexpr (CHAINED) {
                 if (same_src) {
-                    if (tid < p.pre_right_len) smem[p.pre_scratch + N + tid] = p.pre_canon_right ? T(0) + pf_x : pf_x;
+                    if (tid < p.pre_right_len) {
+                        const T x = p.pre_canon_right ? T(0) + pf_x : pf_x;
+                        smem[p.pre_scratch + N + tid] = x;
+                        smem[p.pre_scratch + N + p.pre_right_len + 1 + tid] = -x;   // the operand of the terms with coefficient -1
+                    }
                     if (tid == 0) smem[p.pre_scratch + N + p.pre_right_len] = T(0);   // the zero pair of the padding entries
                 } else {
                     list_fill_scratch<T, THREADS>(p, item, 1, smem + p.pre_scratch, tid);
@@ -1512,8 +1543,11 @@ __host__ __device__ __forceinline__ constexpr int mfma7_k(int kq, int s) {
     return tab[kq][s];
 }
 
+#ifndef GAAST_MFMA7_CHAIN_WAVES
+#define GAAST_MFMA7_CHAIN_WAVES 4   /* the chained kernels: at most 128 registers, four waves per SIMD (A/B switch; 3: the same time) */
+#endif
 template <typename T, int MODE, bool SCALED = false, bool CHAINED = false>
-__global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHAINED ? GAAST_MFMA7_CHAIN_WAVES : 1))) void k_gp_mfma7(DenseArgs<T> p) {
     constexpr bool FAST = MODE >= 1;
     static_assert(!(SCALED && MODE != 0), "a rescaled basis runs on the general staging and stores");
     const T* const left_scale = SCALED ? p.left_scale : nullptr;
@@ -1632,47 +1666,54 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
     }
 
     // CHAINED, register-prefetch path: when the list is R X at n = 8 -- 128 rows of 8 terms, +-1 coefficients -- a lane keeps the
-    // words of its two rows (and the rows' image words) in registers for all its items: list_eval_rows re-reads them from L1 per
-    // item, 18 vector-memory instructions per item and wave beside the two that move data (sand8: 1.43 -> 1.07 ms per 1 M items at
-    // 112 instead of 96 registers; an LDS copy of the words instead: 1.25 ms, and at n = 10 -- where the registers would spill --
-    // the LDS copy LOSES 20 % to the workgroups it displaces).  Same terms, same order, same four-term grouping as
-    // list_eval_rows: the same bits.
-    const bool list_cached = CHAINED && FAST && p.pre_width == 8 && p.pre_rows == 2 * THREADS && p.pre_row_scale == nullptr;
-    uint32_t ce[2][8], crow[2] = {0, 0};
+    // LDS byte addresses of both operands of its 16 terms (and the rows' image words) in registers for all its items; the sign
+    // of a term selects +X or -X in the scratch, as in k_gp_mfma16x4: a term is two reads, one multiplication, one addition
+    // (list_eval_rows: the words re-read from L1 and decoded per item, ~9.5 vector instructions per term, none of which
+    // issues beside a matrix instruction).  Same terms, same order: the same bits.
+    const bool list_cached = CHAINED && FAST && same_src && p.pre_width == 8 && p.pre_rows == 2 * THREADS && p.pre_row_scale == nullptr;
+    const lds_t *cl[2][8], *cr[2][8];   // (pointers, not offsets: the LDS base is a link-time constant the compiler adds per use otherwise)
+    uint32_t crow[2] = {0, 0};
     if constexpr (CHAINED && FAST) {
         if (list_cached) {
+            const uint32_t ll = uint32_t(p.pre_left_len), rl = uint32_t(p.pre_right_len);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 crow[rr] = p.pre_row_map[tid + rr * THREADS];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ce[rr][k] = p.pre_entries[k * (2 * THREADS) + tid + rr * THREADS];
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t e = p.pre_entries[k * (2 * THREADS) + tid + rr * THREADS];
+                    cl[rr][k] = (const lds_t*)(lds + ((uint32_t(p.pre_scratch) + (e & 0x7fffu)) << ES));
+                    cr[rr][k] = (const lds_t*)(lds + ((uint32_t(p.pre_scratch) + ll + ((e >> 16) & 0x7fffu) + ((e >> 31) ? rl + 1u : 0u)) << ES));
+                }
             }
         }
     }
     auto cached_list = [&]() {
-        const char* l = reinterpret_cast<const char*>(smem + p.pre_scratch);
-        const char* r = l + size_t(p.pre_left_len) * sizeof(T);
+        if constexpr (CHAINED && FAST) {
+            // (measured, sand8: both rows' reads before either sum, or all eight steps' matrix operands before the first matrix
+            // instruction, change nothing or lose; the list costs 18 % of the kernel, removed entirely)
+            T acc2[2] = {T(0), T(0)};
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            T acc = T(0);
+            for (int rr = 0; rr < 2; ++rr) {
+                T lv[8], rv[8];
 #pragma unroll
-            for (int k0 = 0; k0 < 8; k0 += 4) {
-                T prod[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t e = ce[rr][k0 + k];
-                    asm volatile("" : "+v"(e));   // the word stays packed in its register (hoisted, its decoded halves cost 32 registers more)
-                    prod[k] = list_flip<T>(*reinterpret_cast<const T*>(l + (e & 0x7fffu) * uint32_t(sizeof(T))) *
-                                               *reinterpret_cast<const T*>(r + ((e >> 16) & 0x7fffu) * uint32_t(sizeof(T))),
-                                           e & 0x80000000u);
+                for (int k = 0; k < 8; ++k) {
+                    lv[k] = *cl[rr][k];
+                    rv[k] = *cr[rr][k];
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc = acc + prod[k];
+                for (int k = 0; k < 8; ++k) acc2[rr] = acc2[rr] + lv[k] * rv[k];
             }
-            const uint32_t pos = (crow[rr] >> 16) & 0x7fffu;
-            const T val = list_flip<T>(acc, crow[rr] & 0x80000000u);
-            smem[A_EL + pos] = val;
-            smem[A_EL + pos + NEG_A_EL] = -val;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const T acc = acc2[rr];
+                uint32_t w = crow[rr];
+                asm volatile("" : "+v"(w));
+                const uint32_t pos = (w >> 16) & 0x7fffu;
+                const T val = list_flip<T>(acc, w & 0x80000000u);
+                smem[A_EL + pos] = val;
+                smem[A_EL + pos + NEG_A_EL] = -val;
+            }
         }
     };
     auto one_item = [&](int64_t item, Pf& f) {
@@ -1695,7 +1736,11 @@ __global__ __launch_bounds__(64) void k_gp_mfma7(DenseArgs<T> p) {
             }
             if constexpr (CHAINED) {
                 if (same_src) {
-                    if (tid < p.pre_right_len) smem[p.pre_scratch + N + tid] = p.pre_canon_right ? T(0) + f.x : f.x;
+                    if (tid < p.pre_right_len) {
+                        const T x = p.pre_canon_right ? T(0) + f.x : f.x;
+                        smem[p.pre_scratch + N + tid] = x;
+                        smem[p.pre_scratch + N + p.pre_right_len + 1 + tid] = -x;   // the operand of the terms with coefficient -1
+                    }
                     if (tid == 0) smem[p.pre_scratch + N + p.pre_right_len] = T(0);   // the zero pair of the padding entries
                 } else {
                     list_fill_scratch<T, THREADS>(p, item, 1, smem + p.pre_scratch, tid);

@@ -157,6 +157,12 @@ struct Step {
     void* jit_module = nullptr;
     void* jit_function = nullptr;
     std::vector<char> jit_code;   // the hiprtc code object jit_module was loaded from: kept until the module is unloaded
+    // the same source compiled with floating-point contraction (l * r + acc as ONE fused multiply-add: fewer roundings than the
+    // reference, so within the tolerance contract but not its bits): built only without GAAST_FLAG_EXACT_ORDER, launched only when
+    // an item's arithmetic outweighs its bytes (runtime.hip: run_jit -- in practice: operands shared by all items)
+    void* jit_module_fma = nullptr;
+    void* jit_function_fma = nullptr;
+    std::vector<char> jit_code_fma;
     // launch configuration, fixed once at gaast_hip_program_create (runtime.hip: prepare_step): kernel, block
     // size, dynamic LDS, persistent-grid size.  ELL products pick kern[log2(items per pass)] by batch.
     const void* kern[4] = {nullptr, nullptr, nullptr, nullptr};

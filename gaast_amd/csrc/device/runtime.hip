@@ -106,9 +106,11 @@ void release_plan_resources(Plan& plan) {
             *p = nullptr;
         }
         if (s.jit_module) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module));
-        s.jit_module = nullptr;
-        s.jit_function = nullptr;
+        if (s.jit_module_fma) (void)hipModuleUnload(static_cast<hipModule_t>(s.jit_module_fma));
+        s.jit_module = s.jit_module_fma = nullptr;
+        s.jit_function = s.jit_function_fma = nullptr;
         std::vector<char>().swap(s.jit_code);   // only after the unload: the image outlives the module built from it
+        std::vector<char>().swap(s.jit_code_fma);
     }
 }
 
@@ -737,10 +739,11 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
 }
 
 // hiprtc specialisation of a fused plan; on any failure the LDS interpreter kernel stays in charge
-bool jit_compile(Step& s, const std::string& source, const char* entry, std::string* log) {
+// (contract: the variant with fused multiply-adds, kept beside the exact one -- Step::jit_function_fma)
+bool jit_compile(Step& s, const std::string& source, const char* entry, std::string* log, bool contract = false) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, source.c_str(), "gaast_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", contract ? "-ffp-contract=fast" : "-ffp-contract=off"};
     const hiprtcResult res = hiprtcCompileProgram(prog, 3, opts);
     if (res != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -771,10 +774,25 @@ bool jit_compile(Step& s, const std::string& source, const char* entry, std::str
         (void)hipModuleUnload(mod);
         return false;
     }
-    s.jit_code = std::move(code);
-    s.jit_module = mod;
-    s.jit_function = fn;
+    if (contract) {
+        s.jit_code_fma = std::move(code);
+        s.jit_module_fma = mod;
+        s.jit_function_fma = fn;
+    } else {
+        s.jit_code = std::move(code);
+        s.jit_module = mod;
+        s.jit_function = fn;
+    }
     return true;
+}
+
+// When does the contracted variant of a specialised kernel pay?  An item costs ~2 vector instructions per comp-mul (4 cycles per
+// wave instruction and SIMD, 64 items per wave, 1,024 SIMDs at 2.4 GHz) and `bytes` of HBM traffic at 8 TB/s; below 0.6 of the
+// traffic time the arithmetic hides behind the rows (cl41: 336 comp-muls, 296 B: 0.46 -- measured 0.78-0.84 of HBM with the
+// exact code), above it the vector ALUs are the bound (cl41 with one shared rotor: 168 B: 0.81 -- 79 % busy, 0.66 of HBM).
+bool arithmetic_bound(uint64_t comp_muls, double bytes) {
+    const double valu_ps = double(comp_muls) * 2.0 * 4.0 / 64.0 / (1024.0 * 2.4e9) * 1e12, hbm_ps = bytes / 8e12 * 1e12;
+    return valu_ps > 0.6 * hbm_ps;
 }
 
 template <typename T>
@@ -804,9 +822,19 @@ int run_jit(const Step& s, const Plan& plan, const std::vector<Bound>& in_bound,
     if (s.jit_persistent > 0) blocks = unsigned(std::min<int64_t>(blocks, int64_t(g_num_cu) * std::min(s.jit_persistent, 4)));   // persistent workgroups
     // (the argument block -- args, ptrs, strides and the locals they point at -- only has to live until this call returns:
     //  hipModuleLaunchKernel copies the kernel arguments into the dispatch packet's kernarg segment at call time)
-    HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(s.jit_function), blocks, 1, 1, threads, 1, 1, 0, g_stream,
-                                  args.data(), nullptr));
-    (void)plan;
+    void* fn = s.jit_function;
+    if (s.jit_function_fma) {
+        // tolerance mode: the rows this launch really moves -- an operand shared by all items moves none, and only then does the
+        // contracted variant run (a program over batched operands only keeps the reference's bits by default, as before)
+        double bytes = double(plan.out_layout.row_len) * sizeof(T);
+        bool shared = false;
+        for (size_t i = 0; i < s.fused_inputs.size(); ++i) {
+            if (strides[i] != 0) bytes += double(plan.input_layouts[size_t(s.fused_inputs[i].slot)].row_len) * sizeof(T);
+            else shared = true;
+        }
+        if (shared && arithmetic_bound(s.n_entries, bytes)) fn = s.jit_function_fma;
+    }
+    HIP_TRY(hipModuleLaunchKernel(static_cast<hipFunction_t>(fn), blocks, 1, 1, threads, 1, 1, 0, g_stream, args.data(), nullptr));
     return GAAST_OK;
 }
 
@@ -993,6 +1021,13 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, s.jit_source, "gaast_jit", &log);
             if (ok)
                 s.name = "ast_jit" + s.name.substr(s.name.find('[')) + (s.jit_items ? " slab in LDS" : "");
+            // tolerance mode, one item per thread, and arithmetic-bound at least when every operand is shared by all items: the
+            // contracted variant too (run_jit picks per launch, by the operands bound)
+            if (ok && !(desc->flags & GAAST_FLAG_EXACT_ORDER) && !s.jit_items && !prog->plan.has_explog &&
+                arithmetic_bound(s.n_entries, double(prog->plan.out_layout.row_len) * dtype_size(prog->plan.dtype))) {
+                std::string log2;
+                if (jit_compile(s, s.jit_source, "gaast_jit", &log2, true)) s.name += " | fused multiply-adds under shared operands";
+            }
             else if (!log.empty())
                 g_err = "hiprtc: " + log;  // informational: the interpreter kernel (or an unfused plan) runs instead
             std::string().swap(s.jit_source);
@@ -1058,7 +1093,8 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             // the list's operand rows of every item a workgroup stages at once, after the kernel's own images
             s.pre_scratch_off = (s.lds + 15) / 16 * 16;
             const size_t items = size_t(s.items_per_block > 0 ? s.items_per_block : 1);
-            s.lds = s.pre_scratch_off + items * size_t(s.pre_left_len + s.pre_right_len + 1) * dtype_size(plan.dtype);   // + the zero pair
+            // + the zero pair; the one-item matrix kernels keep the list's right row twice (+x, -x: a term's sign is an address)
+            s.lds = s.pre_scratch_off + (items * size_t(s.pre_left_len + s.pre_right_len + 1) + (items == 1 ? size_t(s.pre_right_len) : 0)) * dtype_size(plan.dtype);
             if (s.lds > g_max_lds) {
                 g_chain_too_big = true;
                 return set_err(GAAST_ERR_UNIMPLEMENTED, "chained product does not fit in LDS (" + s.name + ")");

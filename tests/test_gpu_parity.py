@@ -101,6 +101,17 @@ def test_cfg5_sandwich_batched_bit_exact(g1, shared_r, flags):
     want, omask = oracle_eval_batch(build, CGA, rows, batch)
     got, hmask, spec = hip_eval_batch(build, CGA, rows, batch, flags=flags)
     assert hmask == omask
+    if shared_r and flags == 0:
+        # round 4: the rotor is shared by all items, the program is arithmetic-bound (336 / 160 comp-muls against 168 / 80 bytes per
+        # item) and nothing asks for the reference's bits: the specialised kernel's contracted variant runs (l * r + acc as one fused
+        # multiply-add: one rounding per term instead of two).  Within 4 eps sum |terms| -- bounded here by (sum |R_i|)^2 sum |X_j| --
+        # and, with GAAST_FLAG_EXACT_ORDER, the bits again.
+        assert any("fused multiply-adds under shared operands" in l for l in spec.launches()), spec.launches()
+        bound = 4 * np.finfo(np.float64).eps * np.abs(rows[0]).sum() ** 2 * np.abs(rows[1]).sum(axis=1)
+        assert np.all(np.abs(got - want) <= bound[:, None]), float(np.abs(got - want).max())
+        assert not np.array_equal(got, want)   # (the variant is really the one that ran)
+        got, hmask, spec = hip_eval_batch(build, CGA, rows, batch, flags=ga.FLAG_EXACT_ORDER)
+        assert not any("fused multiply-adds" in l for l in spec.launches()), spec.launches()
     assert np.array_equal(got, want)
     # Q4: the debug-build behaviour of the reference is a panic, reported as a status
     with pytest.raises(ga.GaastError) as ei:

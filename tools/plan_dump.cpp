@@ -43,6 +43,12 @@ static void dump(const char* what, gaast_expr_t e, int n, int dtype, uint32_t fl
 int main(int argc, char** argv) {
     const uint32_t flags = argc > 1 ? uint32_t(std::strtoul(argv[1], nullptr, 0)) : 0u;
     g_dump_dir = argc > 2 ? argv[2] : nullptr;
+    {   // BASELINE configs[4]: the rotor sandwich R X ~R at n = 5 (one fused launch)
+        const int n = 5;
+        gaast_expr_t r = gaast_expr_input(0, even_mask(n), n), x = gaast_expr_input(1, 0x2, n);
+        gaast_expr_t e = gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC);
+        dump("sandwich", e, n, GAAST_F64, flags);
+    }
     for (int n : {8, 12}) {
         {   // vinv: a.rev() * a.norm_sq().sinv(), a even (expr.rs:363-371)
             gaast_expr_t a = gaast_expr_input(0, even_mask(n), n);
