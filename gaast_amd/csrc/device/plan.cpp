@@ -1995,6 +1995,10 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     // (few long rows) for rows2 * split * ipb lanes; two or more workgroups per CU: 256 threads each
     int64_t threads = 2 * used <= lds_cap ? 256 : 512;
     threads = std::max<int64_t>(threads, std::min<int64_t>(1024, (rows2 * split * ipb + 63) / 64 * 64));
+    // whole multiples of 256: the waves of a workgroup are dealt round-robin to the CU's four SIMDs, and every phase ends at a
+    // barrier -- 9 or 10 waves leave one SIMD with three where the others have two (measured: sand9g1 576 -> 768 threads +6 %,
+    // sand10g1 640 -> 768 +2 %; 1,024 where list 2 does not ask for them: -3 % / -23 %)
+    threads = std::min<int64_t>(1024, (threads + 255) / 256 * 256);
     const int64_t w1s = ent1_mode == 1 ? w1 : w1p;   // words per row of list 1's table
     // tables
     c.cj_ent1.assign(size_t(rows1 * w1s), 0u);
@@ -2041,6 +2045,9 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     bool pos1_linear = true;   // row k of list 1 is component k of the mid row (the usual case): no table, no load
     for (int64_t row = 0; row < rows1; ++row) pos1_linear = pos1_linear && int64_t(w.u32_b[size_t(row)]) == row;
     def("POS1_LINEAR", pos1_linear ? 1 : 0);
+    // EXACT: every product rounded, then added (eval.rs:82), rows summed whole -- the reference's bits.  Otherwise (the default,
+    // the dense products' tolerance contract): rows of list 2 in slices, and l * r + acc as one fused multiply-add
+    def("EXACT", (plan.flags & GAAST_FLAG_EXACT_ORDER) ? 1 : 0);
     def("SPLIT", split); def("WS", w2 / split);                    // slices per row of list 2, terms per slice
     def("PASSES2", (rows2 * split + threads / ipb - 1) / (threads / ipb));   // (row, slice) pairs of list 2 per thread
     // terms of list 2 in flight per register set: the registers of two waves per SIMD (512 threads) hold 8 f64 / 16 f32 terms twice; more
@@ -2065,6 +2072,11 @@ __device__ __forceinline__ T with_hi(T v, u32 hi) { return __builtin_bit_cast(fl
 __device__ __forceinline__ u32 hi_of(T v) { return __builtin_bit_cast(u32, v); }
 __device__ __forceinline__ T pm_one(u32 hi) { return __builtin_bit_cast(float, hi); }
 #define FMA(a, b, c) __builtin_fmaf(a, b, c)
+#endif
+#if EXACT
+#define MAC(a, b, c) ((c) + (a) * (b))
+#else
+#define MAC(a, b, c) FMA(a, b, c)
 #endif
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 #define LDS(addr) (*(const __attribute__((address_space(3))) T*)(smem + (addr)))
@@ -2275,7 +2287,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             auto sum1 = [&](const T (&lv)[W1], const T (&rv)[W1], int row) {
                 T acc = T(0);
 #pragma unroll
-                for (int t = 0; t < W1; ++t) acc = acc + lv[t] * rv[t];      // (l * r) * (+-1) then +=: the sign rides in the image
+                for (int t = 0; t < W1; ++t) acc = MAC(lv[t], rv[t], acc);   // (l * r) * (+-1) then +=: the sign rides in the image
 #if POS1_LINEAR
                 *(__attribute__((address_space(3))) T*)(smem + base + OFF_MID + row * ESZ) = CANON_MID ? T(0) + acc : acc;
 #else
@@ -2332,8 +2344,12 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             auto sum2 = [&](const T (&mv)[TB], const T (&ov)[TB], const u32 (&sg)[TB]) {
 #pragma unroll
                 for (int t = 0; t < TB; ++t) {
+#if EXACT
                     const T pr_ = mv[t] * ov[t];
                     acc = acc + with_hi(pr_, hi_of(pr_) ^ sg[t]);            // eval.rs:82: (l * r) * (+-1), then +=
+#else
+                    acc = FMA(with_hi(mv[t], hi_of(mv[t]) ^ sg[t]), ov[t], acc);   // tolerance mode: one rounding per term
+#endif
                 }
             };
 #else
@@ -2372,8 +2388,13 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
 #if ENT2_MODE == 2
                 const u32x4 e4 = ent2_quad(row, q0 + t / 2);
                 const u32 e = e4[2 * (t & 1)], sgb = e4[2 * (t & 1) + 1];
+#if EXACT
                 const T pr_ = LDS(base + (e & 0xffffu)) * LDS(base + (e >> 16));
                 acc = acc + with_hi(pr_, hi_of(pr_) ^ sgb);
+#else
+                const T m_ = LDS(base + (e & 0xffffu));
+                acc = FMA(with_hi(m_, hi_of(m_) ^ sgb), LDS(base + (e >> 16)), acc);
+#endif
 #else
                 const u32 e = ent2_quad(row, q0 + t / 4)[t & 3];
                 acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), pm_one((e & 0x80000000u) | ONE_HI), acc);
