@@ -336,6 +336,73 @@ __global__ __launch_bounds__(256) void k_reduce_scale(ReduceScaleArgs<T> p) {
     }
 }
 
+// TOLERANCE MODE of the same step (no GAAST_FLAG_EXACT_ORDER; the dense products' contract, 4 eps sum |terms|) when the reduction is
+// a row's signed sum of squares and the scaled row is that same row -- the versor inverse a.rev() * a.norm_sq().sinv() and its
+// relatives: ONE WAVE PER ITEM, the row read ONCE (k_reduce_scale reads it for the reduction and again for the scaling: 1.5 x the
+// algorithmic traffic at n = 12).  A lane keeps PIECES 16-byte pieces of the row in registers, sums its own terms with fused
+// multiply-adds, the 64 partial sums meet through DPP butterflies (quad permutations, half-row and row mirrors) and four lane
+// reads -- the north-star's "wavefront shuffles for the partial reductions" --, then every lane scales and stores its pieces.
+// signs: [0][lane] bit k = coefficient -1 of the reduction's term on the lane's k-th component, [1][lane] = of the scaling's row.
+template <typename T>
+__device__ __forceinline__ T flip_bit(T v, uint32_t bit31);
+template <>
+__device__ __forceinline__ float flip_bit<float>(float v, uint32_t bit31) { return __uint_as_float(__float_as_uint(v) ^ bit31); }
+template <>
+__device__ __forceinline__ double flip_bit<double>(double v, uint32_t bit31) {
+    return __hiloint2double(__double2hiint(v) ^ int(bit31), __double2loint(v));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_value(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_value(double v) {
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true));
+}
+template <typename T, int PIECES>
+__global__ __launch_bounds__(256) void k_reduce_scale_wave(ReduceScaleArgs<T> p, const uint32_t* __restrict__ signs) {
+    constexpr int EPC = 16 / int(sizeof(T));                   // components per 16-byte piece
+    static_assert(PIECES * EPC <= 32, "a lane's sign bits fit one word");
+    typedef T VT __attribute__((ext_vector_type(EPC)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6), n_waves = int64_t(gridDim.x) * 4;
+    const uint32_t sg1 = signs[lane], sg2 = signs[64 + lane];
+    const T zero = T(0);
+    for (int64_t item = wave; item < p.batch; item += n_waves) {
+        const VT* row = reinterpret_cast<const VT*>(p.l1 + item * p.l1_stride);
+        VT v[PIECES];
+#pragma unroll
+        for (int m = 0; m < PIECES; ++m) v[m] = __builtin_nontemporal_load(row + m * 64 + lane);
+        T acc = zero;
+#pragma unroll
+        for (int m = 0; m < PIECES; ++m) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                T a = v[m][e];
+                if (p.canon_l1 | p.canon_r1 | p.canon_x) a = zero + a;   // (uniform) 0.0 + x of eval.rs:27-31
+                v[m][e] = a;
+                acc = sizeof(T) == 8 ? T(__builtin_fma(double(a), double(flip_bit<T>(a, (sg1 >> (m * EPC + e)) << 31)), double(acc)))
+                                     : T(__builtin_fmaf(float(a), float(flip_bit<T>(a, (sg1 >> (m * EPC + e)) << 31)), float(acc)));
+            }
+        }
+        // 64 partial sums -> every lane: xor 1, xor 2 inside the quads, mirror inside half rows and rows, then the four rows
+        acc = acc + dpp_value<0xB1>(acc);     // quad_perm [1,0,3,2]
+        acc = acc + dpp_value<0x4E>(acc);     // quad_perm [2,3,0,1]
+        acc = acc + dpp_value<0x141>(acc);    // row_half_mirror
+        acc = acc + dpp_value<0x140>(acc);    // row_mirror
+        T s = ((lane_value(acc, 0) + lane_value(acc, 16)) + lane_value(acc, 32)) + lane_value(acc, 48);
+        if (p.op == 1) s = T(1) / s;
+        else if (p.op == 2) s = sizeof(T) == 8 ? T(__builtin_sqrt(double(s))) : T(__builtin_sqrtf(float(s)));
+        if (p.canon_s) s = zero + s;
+        VT* orow = reinterpret_cast<VT*>(p.out + item * p.out_stride);
+#pragma unroll
+        for (int m = 0; m < PIECES; ++m) {
+            VT o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = zero + flip_bit<T>(v[m][e] * s, (sg2 >> (m * EPC + e)) << 31);   // 0.0 + (l * r) * (+-1)
+            __builtin_nontemporal_store(o, orow + m * 64 + lane);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_elementwise: a RUN of element-wise arms on one buffer -- GradedObj copies / additions (eval.rs:45-50 -> graded.rs:67-78), the
 // sign arms Negation / Reverse / GradeInvolution (eval.rs:55-60, 87-102 -> graded.rs:61-65) -- and, optionally, the product of

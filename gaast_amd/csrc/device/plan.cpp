@@ -2748,6 +2748,44 @@ static void fuse_reduce_scale(Plan& plan) {
         }
         f.beta = 0;
         f.n_entries = p1.n_entries + p2.n_entries;
+        // tolerance mode: can a wave keep the row in registers and read it once (k_reduce_scale_wave)?  The reduction must be one term
+        // per component, (i, i), coefficient +-1, in any order; the scaling one row per component in place (x offset = out offset),
+        // +-1; the row a whole number of 64 x 16 bytes with at most 32 components per lane.  (Whether the three rows ARE one row is
+        // known when they are bound: run_step.)
+        if (!(plan.flags & GAAST_FLAG_EXACT_ORDER) && same(p1.a, p1.b) && same(xop, p1.a)) {
+            const size_t per_piece = 64 * (plan.dtype == GAAST_F32 ? 4 : 2);   // components a wave moves per 16-byte load
+            const size_t R = f.u32_a.size();
+            bool okw = R == f.u32_b.size() && R % per_piece == 0 && (R / per_piece) * (per_piece / 64) <= 32 && f.coeff.size() == R && f.coeff_b.size() == R;
+            const size_t pieces = okw ? R / per_piece : 0;
+            okw = okw && (pieces == 1 || pieces == 2 || pieces == 4 || pieces == 8 || pieces == 16);
+            std::vector<uint32_t> sg(128, 0u);
+            std::vector<char> seen1(R, 0), seen2(R, 0);
+            const size_t ec = per_piece / 64;
+            auto place = [&](size_t c, int which) {   // component c of the row -> (lane, bit)
+                const size_t piece = c / ec, e = c % ec, m = piece / 64, lane = piece % 64;
+                sg[size_t(which) * 64 + lane] |= 1u << (m * ec + e);
+            };
+            for (size_t t = 0; okw && t < R; ++t) {
+                const uint32_t li = f.u32_a[t] & 0xffffu, ri = f.u32_a[t] >> 16;
+                okw = li == ri && li < R && !seen1[li] && (f.coeff[t] == 1.0 || f.coeff[t] == -1.0);
+                if (okw) {
+                    seen1[li] = 1;
+                    if (f.coeff[t] < 0) place(li, 0);
+                }
+            }
+            for (size_t r = 0; okw && r < R; ++r) {
+                const uint32_t xo = f.u32_b[r] & 0xffffu, oo = f.u32_b[r] >> 16;
+                okw = xo == oo && xo < R && !seen2[xo] && (f.coeff_b[r] == 1.0 || f.coeff_b[r] == -1.0);
+                if (okw) {
+                    seen2[xo] = 1;
+                    if (f.coeff_b[r] < 0) place(xo, 1);
+                }
+            }
+            if (okw) {
+                f.rs_wave = int(pieces);
+                f.u32_c = std::move(sg);
+            }
+        }
         f.name = "reduce_scale[" + std::to_string(p1.u32_c.size()) + " comp-muls -> scalar" + (op == 1 ? ", 1/s" : op == 2 ? ", sqrt(s)" : "") + ", " +
                  std::to_string(p2.u32_c.size()) + " scaled components]";
         if (plan.node_dead.size() != plan.node_buffers.size()) plan.node_dead.assign(plan.node_buffers.size(), 0);

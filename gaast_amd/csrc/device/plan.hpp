@@ -136,6 +136,8 @@ struct Step {
     int ew_ops = 0, ew_load_first = 0, ew_scale = 0, ew_scalar_off = 0, ew_canon_v = 0, ew_canon_s = 0, ew_s_is_left = 0;
     int rs_op = 0;                       // 0: none, 1: 1 / s, 2: sqrt(s)  (eval.rs:103-110)
     int rs_canon_s = 0;                  // the scalar is re-read as a product operand: 0.0 + s
+    int rs_wave = 0;                     // > 0: tolerance mode, the reduction is a signed sum of squares of the row that is scaled: 16-byte
+                                         // pieces of the row per lane for k_reduce_scale_wave (u32_c = the lanes' sign words)
     int use_mfma6 = 0;   // k_gp_mfma6<T> (n = 6: four 16x16x4 instructions per item, the two top vectors split over the tile's rows and columns)
     int use_mfma7 = 0;   // k_gp_mfma7<T> (n = 7: lo = 3 bits, the top vector split over the two sides of the 16 x 16 tile)
     int mfma16_quads = 0; // ... in f32: the B image in the 16-byte-quad layout

@@ -429,6 +429,23 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         s.threads = 256;
         s.kern[0] = reinterpret_cast<const void*>(&k_reduce_scale<T>);
         s.hip_kernel = "k_reduce_scale<" + tn + ">";
+        if (s.rs_wave) {   // tolerance mode: one wave per item, the row read once -- taken at launch when the three rows are one (run_step)
+            using KernW = void (*)(ReduceScaleArgs<T>, const uint32_t*);
+            KernW kw = nullptr;
+            switch (s.rs_wave) {
+            case 1: kw = &k_reduce_scale_wave<T, 1>; break;
+            case 2: kw = &k_reduce_scale_wave<T, 2>; break;
+            case 4: kw = &k_reduce_scale_wave<T, 4>; break;
+            case 8: kw = &k_reduce_scale_wave<T, 8>; break;
+            case 16:
+                if constexpr (sizeof(T) == 8) kw = &k_reduce_scale_wave<T, 16>;
+                break;
+            default: break;
+            }
+            s.kern[1] = reinterpret_cast<const void*>(kw);
+            if (kw) s.hip_kernel += " | k_reduce_scale_wave<" + tn + "," + std::to_string(s.rs_wave) + "> (lane-parallel sums) when the rows are one";
+            else s.rs_wave = 0;
+        }
         return resident_blocks(s.kern[0], s.threads, 0, &s.blocks_per_cu);
     }
     case Step::FUSED: {
@@ -485,6 +502,17 @@ int run_step(const Step& s, const Bound& res, const Bound& a, const Bound& b, co
         q.s_is_left = s.list_chain == 1;
         q.op = s.rs_op;
         q.batch = batch;
+        if (s.rs_wave && s.kern[1] && a.ptr == b.ptr && a.ptr == pre_a.ptr && a.stride == b.stride && a.stride == pre_a.stride &&
+            (reinterpret_cast<uintptr_t>(a.ptr) & 15u) == 0 && (size_t(a.stride) * sizeof(T)) % 16 == 0 &&
+            (reinterpret_cast<uintptr_t>(res.ptr) & 15u) == 0 && (size_t(res.stride) * sizeof(T)) % 16 == 0 && res.ptr != a.ptr) {
+            // one wave per item, four per workgroup, persistent
+            using KernW = void (*)(ReduceScaleArgs<T>, const uint32_t*);
+            int64_t blocks = (batch + 3) / 4;
+            blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * 8);
+            hipLaunchKernelGGL(reinterpret_cast<KernW>(const_cast<void*>(s.kern[1])), dim3(unsigned(blocks)), dim3(256), 0, g_stream, q,
+                               static_cast<const uint32_t*>(s.d_c));
+            break;
+        }
         // sixteen items per wave, four waves per workgroup, persistent: as many workgroups as are resident at once
         int64_t blocks = (batch + 63) / 64;
         blocks = std::min<int64_t>(blocks, int64_t(g_num_cu) * (s.blocks_per_cu > 0 ? s.blocks_per_cu : 8));

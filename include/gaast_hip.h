@@ -126,7 +126,15 @@ typedef struct gaast_input_desc {
 
 #define GAAST_FLAG_DEBUG_OVERFLOW 0x1u /* reproduce the debug-build panic of eval.rs:90 (default: release) */
 #define GAAST_FLAG_NO_FUSION 0x2u      /* one kernel per eval.rs arm, every operand materialised (A/B testing) */
-#define GAAST_FLAG_EXACT_ORDER 0x4u    /* never use the dense re-ordered product kernel (bit-exact f64 sums) */
+/* Every sum in the reference's order with its three roundings per term (eval.rs:82): the result is the reference's, bit for bit.
+ * WITHOUT the flag (the default) four things may differ, each within 4 eps sum |terms| per component (8: general metric) of the
+ * reference's result OR closer to the exactly rounded sum than the reference's own sequential sum is:
+ * dense products run on the re-ordered matrix-core kernels; long rows of a list product are summed in slices with fused
+ * multiply-adds; a specialised small program whose arithmetic outweighs its bytes because an operand is SHARED by all items
+ * (batch-1 input) contracts l * r + acc into one fused multiply-add; and the norm of a versor inverse / normalisation too big for
+ * a fused program (n >= 9) is summed by the 64 lanes of a wave in parallel (the row is then read once).  Small programs over
+ * batched operands and element-wise arms keep the reference's bits either way. */
+#define GAAST_FLAG_EXACT_ORDER 0x4u
 #define GAAST_FLAG_NO_MFMA 0x8u        /* dense products stay on the vector-FMA kernel (A/B testing) */
 #define GAAST_FLAG_NO_JIT 0x10u        /* small programs run on the LDS interpreter kernel, not on hiprtc-specialised code */
 /* OPT-IN, not the reference's algorithm: dense geometric products of a non-degenerate algebra (f32:

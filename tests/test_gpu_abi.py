@@ -95,6 +95,11 @@ def test_explicit_dense_list_is_recognised_only_when_it_is_the_geometric_product
     C.memmove(C.byref(muls[1]), C.byref(tmp), C.sizeof(_lib.CompMul))
     assert (muls[0].result_grade, muls[0].result_index) != (muls[1].result_grade, muls[1].result_index)
     got, names = _run_raw(desc, ins, batch, n)
+    # (64 rows of 64 terms: the specialised list kernel; without GAAST_FLAG_EXACT_ORDER its sums use fused multiply-adds since round 4:
+    #  the tolerance contract of every re-ordered kernel, here far inside 1e-12; the reference's bits under the flag, below)
+    assert not any("dense" in x for x in names) and np.allclose(got, want, rtol=0, atol=1e-12)
+    desc.flags = _lib.FLAG_EXACT_ORDER
+    got, names = _run_raw(desc, ins, batch, n)
     assert not any("dense" in x for x in names) and np.array_equal(got, want)
     desc, keep = _raw_program(spec, flags=_lib.FLAG_EXACT_ORDER)      # the host insists on the reference order
     got, names = _run_raw(desc, ins, batch, n)

@@ -657,6 +657,26 @@ def test_the_versor_inverse_beyond_a_fused_slab_is_one_launch(n, dtype, metric):
     got, mask, spec = hip_eval_batch(build, alg, rows, batch, dtype=dtype)
     assert mask == wmask
     assert len(spec.launches()) == 1 and spec.launches()[0].startswith("reduce_scale[") and "k_reduce_scale<" in spec.launches()[0], spec.launches()
+    if metric is None:
+        # +-1 coefficients, the reduction a signed sum of squares of the very row that is scaled: without GAAST_FLAG_EXACT_ORDER one
+        # wave per item keeps the row in registers (read ONCE), lane-parallel partial sums joined by DPP butterflies.  The terms here
+        # are all positive, so the REFERENCE's sequential sum of 2^(n-1) terms is itself up to ~sqrt(terms) eps away from the true
+        # norm (measured: 14 eps at n = 12) while 64 short chains + a butterfly stay within 1 eps of it: the two differ by the
+        # reference's own rounding error.  Asserted: (a) every component within 6 eps of the TRUE value +-a_k / N (N summed
+        # exactly, math.fsum) -- closer than the reference is --, (b) within 32 eps of the reference's, (c) with the flag, the
+        # reference's bits (sixteen items per wave, sequential chains).
+        import math
+        assert "k_reduce_scale_wave<" in spec.launches()[0], spec.launches()
+        eps = float(np.finfo(npdt).eps)
+        a64 = rows64[0]
+        n_true = np.array([math.fsum(r * r) for r in a64])
+        true = np.sign(want) * np.abs(a64) / n_true[:, None]
+        g64 = got.astype(np.float64)
+        assert np.all(np.abs(g64 - true) <= 6 * eps * np.abs(true) + 1e-300), float((np.abs(g64 - true) / (eps * np.abs(true) + 1e-300)).max())
+        assert np.all(np.abs(g64 - want) <= 32 * eps * np.abs(want) + 1e-300), float((np.abs(g64 - want) / (eps * np.abs(want) + 1e-300)).max())
+        assert not np.array_equal(got.astype(np.float64), want)                 # (the re-ordered sum really ran)
+        got, mask, spec = hip_eval_batch(build, alg, rows, batch, dtype=dtype, flags=ga.FLAG_EXACT_ORDER)
+        assert len(spec.launches()) == 1 and "k_reduce_scale<" in spec.launches()[0] and "k_reduce_scale_wave" not in spec.launches()[0], spec.launches()
     assert np.array_equal(got.astype(np.float64), want)
     three, _, spec3 = hip_eval_batch(build, alg, rows, batch, dtype=dtype, flags=ga.FLAG_DEBUG_NO_CHAIN)
     assert len(spec3.launches()) == 3 and np.array_equal(three.astype(np.float64), want), spec3.launches()

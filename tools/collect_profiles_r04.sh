@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence: rocprofv3 --kernel-trace --stats of the bench command per workload, PMC passes (separate, --kernel-trace only),
 # bench JSON lines.  Output under gpurun_out/prof_r04/; `python3 tools/collect_profiles.py r04` files the summaries under profiles/.
-#   tools/collect_profiles_r04.sh stats1 | stats2 | pmc1 | pmc2      (one GPU call each: a call is limited to 20 minutes)
+#   tools/collect_profiles_r04.sh stats1 | stats2 | pmc1 | pmc2 | pmc3      (one GPU call each: a call is limited to 20 minutes)
 phase=${1:-stats1}
 out=gpurun_out/prof_r04
 mkdir -p $out
@@ -44,7 +44,9 @@ stats2)
   stats unary12 --workload unary12
   stats unary12_per_arm --workload unary12 --flags 0x800
   stats vinv12_per_arm --workload vinv12 --flags 0x800
+  stats sand8 --workload sand8
   stats sand9 --workload sand9
+  stats sand10 --workload sand10
   python3 -m pytest tests -m gpu -q > $out/gpu_tests_final.txt 2>&1
   tail -3 $out/gpu_tests_final.txt
   ;;
@@ -64,6 +66,12 @@ pmc2)
   pmc unary12 k_elementwise --workload unary12
   pmc cl41 gaast_jit --workload cl41
   pmc r8 k_gp_mfma16 --workload r8
+  ;;
+pmc3)
+  pmc sand8 k_gp_mfma7 --workload sand8
+  pmc sand9 k_gp_mfma16x4 --workload sand9
+  pmc sand10 k_gp_mfma16x4 --workload sand10
+  pmc sand10g1 gaast_chain --workload sand10g1
   ;;
 esac
 ls $out | head -80
