@@ -27,7 +27,8 @@ namespace gaast {
 // Staging writes the operands IN INSTRUCTION ORDER: the lane that loaded component A[u, a_hi, a_lo] stores it, signed, into
 // slot a_hi of the four lanes (kq, row (u, a_lo ^ kq)) that multiply it, likewise B -- eight 4-byte (8-byte) stores per
 // lane and item -- so that a lane's operands of all four instructions are ONE 16-byte read per operand (f64: two).
-// Missing components (operands that hold only some grades) are slots nobody writes: they stay zero from the initial clear.
+// Missing components (operands that hold only some grades) and vanishing slots (null vectors) are slots nobody writes: they stay
+// zero from the initial clear.
 // Which lane moves which component is the host's choice (plan.cpp: build_map deals full operands by LDS bank; the B stores go
 // out in the slot order i ^ b_lo): no bank conflict on the eight stores.
 // DEPTH items are in flight per wave (two loads each): 32 waves x DEPTH x 512 B per CU hide the HBM latency.
@@ -57,14 +58,15 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
     // LDS (bytes): A image, then B image; f32: lane * 16 + slot * 4; f64: (slot >> 1) * 1024 + lane * 16 + (slot & 1) * 8 -- a
     // lane's 16-byte reads of one half are consecutive over the lanes (no bank conflict)
     constexpr uint32_t IMG = F32 ? 1024u : 2048u;
+    constexpr uint32_t DUMMY = 2u * IMG, PER_WAVE = 2u * IMG + 64u * uint32_t(sizeof(T));   // one element per lane nobody reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // every wave of the workgroup is on its own: its items, its images (no workgroup barrier anywhere)
     constexpr int WAVES = GAAST_MFMA6_WAVES;
-    const int wave_id = int(threadIdx.x) >> 6;
-    lds_u8* lds = (lds_u8*)smem_raw + uint32_t(wave_id) * 2u * IMG;
+    const int wave_id = WAVES == 1 ? 0 : int(threadIdx.x) >> 6;   // (one wave: the item index and every row base stay in scalar registers)
+    lds_u8* lds = (lds_u8*)smem_raw + uint32_t(wave_id) * PER_WAVE;
     typedef __attribute__((address_space(3))) T lds_t;
     const int tid = int(threadIdx.x) & 63;
-    for (int e = tid; e < int(2 * IMG / 4); e += 64) reinterpret_cast<uint32_t*>(smem_raw + size_t(wave_id) * 2 * IMG)[e] = 0u;
+    for (int e = tid; e < int(2 * IMG / 4); e += 64) reinterpret_cast<uint32_t*>(smem_raw + size_t(wave_id) * PER_WAVE)[e] = 0u;
     auto slot_addr = [&](uint32_t lane, uint32_t slot) -> uint32_t {
         return F32 ? lane * 16u + slot * 4u : (slot >> 1) * 1024u + lane * 16u + (slot & 1u) * 8u;
     };
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
     const bool has_a = FAST || tid < p.left_count, has_b = FAST || tid < p.right_count;
     const uint32_t ma = has_a ? p.left_map[tid] : 0u, mb = has_b ? p.right_map[tid] : 0u;
     const uint32_t off_a = (ma & 0xffffu) << ES, off_b = (mb & 0xffffu) << ES;
-    uint32_t wa[4], sa[4], ka[4], wb[4], sb[4], kb[4];   // store address, sign bit, keep mask of the four slots
+    // store address and sign bit of the four slots.  A slot that VANISHES (its blades share a null basis vector) is not written at
+    // all -- its store goes to the lane's dummy element, the slot keeps the zero of the initial clear: no mask per value and item
+    uint32_t wa[4], sa[4], wb[4], sb[4];
+    const uint32_t dummy = DUMMY + uint32_t(tid) * uint32_t(sizeof(T));
     {
         const uint32_t a = (ma >> 16) & 63u, u = a >> 4, ah = (a >> 2) & 3u, al = a & 3u;
 #pragma unroll
@@ -85,9 +90,8 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
             const uint32_t par = group_reorder_parity(al, j) ^ (uint32_t(__builtin_popcount(al & j & NEG_L)) & 1u) ^
                                  (uint32_t(__builtin_popcount(u)) & uint32_t(__builtin_popcount(j) + __builtin_popcount(ah)) & 1u) ^
                                  (uint32_t(__builtin_popcount(ah)) & uint32_t(__builtin_popcount(j)) & 1u);
-            wa[j] = slot_addr(j * 16u + tile_row(u, x), ah);
+            wa[j] = (al & j & Z_L) ? dummy : slot_addr(j * 16u + tile_row(u, x), ah);
             sa[j] = ((par & 1u) << 31) ^ (ma & 0x80000000u);
-            ka[j] = (al & j & Z_L) ? 0u : ~0u;
         }
         const uint32_t b = (mb >> 16) & 63u, v = b >> 4, bh = (b >> 2) & 3u, bl = b & 3u;
 #pragma unroll
@@ -95,9 +99,8 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
             const uint32_t s = i ^ bl;       // over the slots -- with one slot per instruction they share 8 of the 32 banks
             const uint32_t y = bh ^ s;
             const uint32_t par = group_reorder_parity(s, bh) ^ (uint32_t(__builtin_popcount(s & bh & NEG_H)) & 1u);
-            wb[i] = IMG + slot_addr(bl * 16u + 4u * y + v, s);
+            wb[i] = (s & bh & Z_H) ? dummy : IMG + slot_addr(bl * 16u + 4u * y + v, s);
             sb[i] = ((par & 1u) << 31) ^ (mb & 0x80000000u);
-            kb[i] = (s & bh & Z_H) ? 0u : ~0u;
         }
     }
     const T scale_a = (SCALED && has_a && p.left_scale) ? p.left_scale[tid] : T(1);
@@ -111,6 +114,8 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
                              (uint32_t(__builtin_popcount(u & v & NEG_T)) & 1u);
         su[u] = (par & 1u) << 31;
         ku[u] = (u & v & Z_T) ? 0u : ~0u;
+        asm volatile("" : "+v"(ku[u]));   // opaque: (value ^ sign) & keep is ONE v_bitop3 then (seen as a select, the compiler builds compare +
+                                          // v_cndmask pairs per item)
     }
     // the lane ends with component (w = v, y, x = kq)
     const uint32_t comp = (v << 4) | (y << 2) | kq;
@@ -157,9 +162,9 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the clear
 
     auto one_item = [&](int64_t item, T& fa, T& fb) {
+        // (the reference's 0.0 + x on a product operand, eval.rs:27-31, only turns -0.0 into +0.0: a zero contributes the same to a
+        //  re-ordered sum whose accumulators start from +0.0 -- not spent here: it cost an addition and a select per value)
         T va = fa, vb = fb;
-        if (p.canon_left) va = T(0) + va;     // the reference's zero-init + add_grades_from copy of a product operand (eval.rs:27-31)
-        if (p.canon_right) vb = T(0) + vb;
         if (SCALED) {
             va = va * scale_a;
             vb = vb * scale_b;
@@ -170,11 +175,11 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
         }
         if (has_a) {   // (FAST: every lane)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(lds_t*)(lds + wa[j]) = apply(va, sa[j], ka[j]);
+            for (int j = 0; j < 4; ++j) *(lds_t*)(lds + wa[j]) = MM::flip(va, sa[j]);
         }
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) *(lds_t*)(lds + wb[s]) = apply(vb, sb[s], kb[s]);
+            for (int s = 0; s < 4; ++s) *(lds_t*)(lds + wb[s]) = MM::flip(vb, sb[s]);
         }
         lds_barrier<64>();   // one wave: the LDS executes its instructions in order
         T av[4], bv[4];
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(64 * GAAST_MFMA6_WAVES) void k_gp_mfma6(DenseArgs<T
         if (SCALED) val = val * osc;
         val = MM::flip(val, osg);
         if constexpr (FAST) {
-            const T canon = T(0) + val;             // a zero result under a negated reordering sign stays +0.0
-            val = osg ? canon : val;
+            val = T(0) + val;                       // a zero result under a negated reordering sign stays +0.0 (res itself is never -0.0:
+                                                    // the accumulators start from +0.0)
             uint32_t oo = ooff;
             asm volatile("" : "+v"(oo));
             __builtin_nontemporal_store(val, reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(p.out + item * p.out_stride) + oo));

@@ -369,7 +369,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             // k_gp_mfma6<T>: one wave per item, persistent single-wave workgroups, 2 KiB (f32) / 4 KiB (f64) of operand images
             s.threads = 64 * GAAST_MFMA6_WAVES;
             s.items_per_block = GAAST_MFMA6_WAVES;
-            s.lds = size_t(is_f64 ? 4096 : 2048) * GAAST_MFMA6_WAVES;
+            s.lds = (size_t(is_f64 ? 4096 : 2048) + 64 * sizeof(T)) * GAAST_MFMA6_WAVES;   // + a dummy element per lane (stores of vanishing slots)
             using KernD = void (*)(DenseArgs<T>);
             // [0]: any operands (partial grade sets, projected or accumulated results); [1]: full operands, every blade produced, nothing
             // accumulated -- straight-line item loop with counted waits
