@@ -28,6 +28,14 @@ static void dump(const char* what, gaast_expr_t e, int n, int dtype, uint32_t fl
                 plan.steps.size(), plan.node_buffers.size(), plan.unsupported.empty() ? "" : (" UNSUPPORTED: " + plan.unsupported).c_str());
     for (const gaast::Step& s : plan.steps) {
         std::printf("    %s%s%s\n", s.name.c_str(), s.chain_jit ? "  [gaast_chain]" : "", s.jit_source.empty() ? "" : (s.jit_items ? "  [gaast_jit, slab in LDS]" : "  [gaast_jit]"));
+        if (g_dump_dir && !s.chain_jit_source.empty()) {
+            char path[512];
+            std::snprintf(path, sizeof path, "%s/%s_n%d_chain.hip", g_dump_dir, what, n);
+            if (FILE* f = std::fopen(path, "w")) {
+                std::fputs(s.chain_jit_source.c_str(), f);
+                std::fclose(f);
+            }
+        }
         if (g_dump_dir && !s.jit_source.empty()) {
             char path[512];
             std::snprintf(path, sizeof path, "%s/%s_n%d.hip", g_dump_dir, what, n);
