@@ -1092,7 +1092,13 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
     //  -- for plans of SEVERAL steps only: a single big list is better off on k_product_ell (twice the terms per second)
     const size_t interp_budget = plan.steps.size() >= 2 ? kInterpLdsBytes : size_t(48 * 1024);
     const bool interp_ok = !(slab > 4095 || size_t(slab) * elem > 32767 || size_t(slab) * elem * 64 > interp_budget) && !plan.has_explog;
-    const int jit_slab_limit = plan.dtype == GAAST_F32 ? 200 : 160;
+    // One item per thread, the slab in registers: up to 160 (f64) / 200 (f32) elements always; up to 256 / 320 ON TRIAL -- the
+    // compiler keeps only the LIVE values in registers, the projection (v & bv) & bv.vinv() at n = 12 (slab 171) compiles to 222
+    // registers and runs at 0.75 of the HBM roof against 0.44 with its slabs in LDS, the versor inverse at n = 8 (slab 259: the
+    // whole row is live until it is scaled) to 310 with one wave per SIMD and 0.46 against 0.67.  The runtime measures the compiled
+    // kernel's occupancy and rebuilds the plan with GAAST_FLAG_INTERNAL_SMALL_REG_SLAB when the trial fails.
+    const int jit_slab_small = plan.dtype == GAAST_F32 ? 200 : 160;
+    const int jit_slab_limit = (plan.flags & GAAST_FLAG_INTERNAL_SMALL_REG_SLAB) ? jit_slab_small : (plan.dtype == GAAST_F32 ? 320 : 256);
     const bool jit_allowed = !(plan.flags & GAAST_FLAG_NO_JIT) && slab <= jit_slab_limit;
     if (!interp_ok && !jit_allowed) return false;
     if (slab_probe) {
@@ -1550,6 +1556,7 @@ bool try_fuse(Plan& plan, int* slab_probe = nullptr) {
         src += "}\n";
         f.jit_threads = threads;
         f.jit_source = std::move(src);
+        f.jit_reg_trial = slab > jit_slab_small;
     } else if (!(plan.flags & GAAST_FLAG_NO_JIT) && interp_ok && !plan.has_explog && entries <= 2048 &&
                size_t(slab | 1) * elem * 64 + 64 <= kLdsBytes) {
         // ---- MEDIUM programs (round 4): the slab is beyond the registers of the specialised kernel above (160 / 200 elements) but the

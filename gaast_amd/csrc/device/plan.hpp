@@ -9,6 +9,10 @@
 #include "../common/comp_mul_table.hpp"
 #include "gaast_hip.h"
 
+// internal (not in include/gaast_hip.h): the one-item-per-thread specialised kernel is limited to slabs of 160 / 200 elements -- set by
+// program_create_impl when a bigger slab's trial compilation needs more than half of a SIMD's registers
+#define GAAST_FLAG_INTERNAL_SMALL_REG_SLAB 0x40000000u
+
 namespace gaast {
 
 enum class BufKind : int { NODE = 0, INPUT = 1, OUT = 2 };
@@ -155,6 +159,8 @@ struct Step {
     int jit_items = 0;        // items per workgroup of the specialised kernel when it is not one per thread (the slab-in-LDS form: 64)
     int jit_threads = 256;    // workgroup size of the specialised kernel (64: one wave per workgroup, coalesced row I/O through LDS)
     int fused_jit_only = 0;   // the slab is too big for the LDS interpreter: runs only as the hiprtc-specialised kernel
+    int jit_reg_trial = 0;    // one item per thread with a slab beyond 160 / 200 elements: kept only if the compiled kernel leaves two
+                              // waves per SIMD (runtime.hip: program_create_impl); else the plan is rebuilt with the slabs in LDS
     std::string jit_source;   // FUSED: the plan as straight-line HIP (compiled with hiprtc at program_create)
     void* jit_module = nullptr;
     void* jit_function = nullptr;

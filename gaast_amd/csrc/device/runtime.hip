@@ -1040,7 +1040,8 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
     if (!prog->plan.unsupported.empty()) return set_err(GAAST_ERR_UNIMPLEMENTED, prog->plan.unsupported);
     // hiprtc specialisation of fused plans, before anything is uploaded: a plan that can only run as the
     // specialised kernel is rebuilt without run-time compilation if the compiler is not available
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    uint32_t rebuild_flags = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
         bool rebuild = false;
         for (Step& s : prog->plan.steps) {
             if (s.kind != Step::FUSED || s.jit_source.empty()) continue;
@@ -1049,21 +1050,36 @@ static int program_create_impl(const gaast_program_desc* desc, gaast_hip_program
             const bool ok = (desc->flags & GAAST_FLAG_DEBUG_JIT_FAILS) ? false : jit_compile(s, s.jit_source, "gaast_jit", &log);
             if (ok)
                 s.name = "ast_jit" + s.name.substr(s.name.find('[')) + (s.jit_items ? " slab in LDS" : "");
+            else if (!log.empty())
+                g_err = "hiprtc: " + log;  // informational: the interpreter kernel (or an unfused plan) runs instead
+            bool trial_failed = false;
+            if (ok && s.jit_reg_trial) {
+                // a slab beyond 160 / 200 elements in registers, on trial (plan.cpp: try_fuse): the compiled kernel has to leave two
+                // waves per SIMD (eight single-wave workgroups per CU), else the plan is rebuilt with the slabs in LDS
+                int per_cu = 0;
+                trial_failed = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, static_cast<hipFunction_t>(s.jit_function), s.jit_threads, 0) != hipSuccess ||
+                               per_cu * (s.jit_threads / 64) < 8;
+                if (trial_failed) {
+                    rebuild = true;
+                    rebuild_flags |= GAAST_FLAG_INTERNAL_SMALL_REG_SLAB;
+                }
+            }
             // tolerance mode, one item per thread, and arithmetic-bound at least when every operand is shared by all items: the
             // contracted variant too (run_jit picks per launch, by the operands bound)
-            if (ok && !(desc->flags & GAAST_FLAG_EXACT_ORDER) && !s.jit_items && !prog->plan.has_explog &&
+            if (ok && !trial_failed && !(desc->flags & GAAST_FLAG_EXACT_ORDER) && !s.jit_items && !prog->plan.has_explog &&
                 arithmetic_bound(s.n_entries, double(prog->plan.out_layout.row_len) * dtype_size(prog->plan.dtype))) {
                 std::string log2;
                 if (jit_compile(s, s.jit_source, "gaast_jit", &log2, true)) s.name += " | fused multiply-adds under shared operands";
             }
-            else if (!log.empty())
-                g_err = "hiprtc: " + log;  // informational: the interpreter kernel (or an unfused plan) runs instead
             std::string().swap(s.jit_source);
-            if (!ok && s.fused_jit_only) rebuild = true;
+            if (!ok && s.fused_jit_only) {
+                rebuild = true;
+                rebuild_flags |= GAAST_FLAG_NO_JIT;
+            }
         }
         if (!rebuild) break;
         gaast_program_desc d2 = *desc;
-        d2.flags |= GAAST_FLAG_NO_JIT;
+        d2.flags |= rebuild_flags;
         release_plan_resources(prog->plan);  // modules already loaded for other fused steps
         prog->plan = Plan();
         try {

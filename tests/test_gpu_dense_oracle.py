@@ -683,7 +683,7 @@ def test_the_versor_inverse_beyond_a_fused_slab_is_one_launch(n, dtype, metric):
     assert any("k_scalar_unary" in l or "scalar_inversion" in l for l in spec3.launches()), spec3.launches()
 
 
-@pytest.mark.parametrize("name,dtype", [("vinv8", ga.F64), ("vinv8", ga.F32), ("proj12", ga.F64), ("unary12", ga.F64)])
+@pytest.mark.parametrize("name,dtype", [("vinv8", ga.F64), ("vinv8", ga.F32), ("proj12", ga.F64), ("proj12", ga.F32), ("unary12", ga.F64)])
 def test_medium_programs_run_as_straight_line_code_over_slabs_in_lds(name, dtype):
     """Programs whose slab is beyond the registers of the specialised kernel (160 / 200 elements) but short (<= 2048 comp-muls): the
     interpreter's schedule as hiprtc-compiled straight-line code over slabs that stay in LDS (round 4; the LDS interpreter remains the
@@ -708,7 +708,14 @@ def test_medium_programs_run_as_straight_line_code_over_slabs_in_lds(name, dtype
     want, wmask = oracle_eval_batch(build, n, rows64, batch, mode=ogm.EVAL_RELEASE if dtype == ga.F64 else ogm.EVAL_F32)
     got, mask, spec = hip_eval_batch(build, n, rows, batch, dtype=dtype)
     assert mask == wmask
-    assert len(spec.launches()) == 1 and spec.launches()[0].startswith("ast_jit[") and "slab in LDS" in spec.launches()[0], spec.launches()
+    assert len(spec.launches()) == 1 and spec.launches()[0].startswith("ast_jit["), spec.launches()
+    # where the slab lives is decided by a TRIAL compilation (round 4): up to 256 / 320 elements one item per thread is tried first and
+    # kept when the compiled kernel leaves two waves per SIMD -- the projection at n = 12 (slab 171: 222 registers; 0.75 of the HBM
+    # roof against 0.44 with its slabs in LDS); the versor inverse at n = 8 (slab 259: the whole row is live until it is scaled, 310
+    # registers) falls back to slabs in LDS, as does anything bigger
+    in_lds = "slab in LDS" in spec.launches()[0]
+    if name == "proj12" or (name, dtype) == ("vinv8", ga.F64):
+        assert in_lds == (name != "proj12"), spec.launches()
     assert np.array_equal(got.astype(np.float64), want)
     interp, _, spec2 = hip_eval_batch(build, n, rows, batch, dtype=dtype, flags=ga.FLAG_NO_JIT)
     assert len(spec2.launches()) == 1 and spec2.launches()[0].startswith("ast_fused[") and np.array_equal(interp.astype(np.float64), want), spec2.launches()
