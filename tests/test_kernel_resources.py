@@ -73,6 +73,10 @@ def test_spills_stay_out_of_the_hot_kernels(kernels):
     ("k_gp_mfma16x4<double, false, 12, 2, false, false>", 4),     # r12d: 16 waves per item, one item per CU
     ("k_gp_spinor12s<5, true>", 2),
     ("k_gp_mfma7<float, 2, false, false>", 8), ("k_gp_mfma7<double, 2, false, false>", 6),   # one wave per item: the waves of a SIMD are its latency hiding
+    # round 4
+    ("k_gp_mfma6<float, false, true>", 8), ("k_gp_mfma6<double, false, true>", 5),           # n = 6: one wave per item, four items in flight each
+    ("k_gp_mfma16x4<double, false, 8, 2, false, true>", 2),      # sand9: the list's 72 operand addresses in registers beside the unrolled matrix loop
+    ("k_gp_mfma7<double, 2, false, true>", 4), ("k_gp_mfma7<float, 2, false, true>", 4),     # sand8: amdgpu_waves_per_eu(4)
 ])
 def test_hot_kernels_keep_their_occupancy(kernels, prefix, waves):
     for name, k in _find(kernels, prefix).items():
