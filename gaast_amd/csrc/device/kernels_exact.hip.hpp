@@ -440,17 +440,19 @@ constexpr int ELEMENTWISE_MAX_OPS = 8;      // statements per component of one p
 // offsets and coefficient are decoded once, and per step the operand loads of four items are all in flight before the first
 // statement runs (per (item, component) threads re-read the tables for every element: 0.27 of the HBM roof; one item per
 // step with its loads behind the previous item's store: 0.20).  Consecutive threads hold consecutive components: coalesced rows.
-template <typename T>
+// NOPS: statements per component this instantiation holds (4: half the registers of 8 -- the loaded operands of U items x NOPS
+// statements are live at once --, five waves per SIMD instead of three: the kernel is bound by the loads it keeps in flight)
+template <typename T, int NOPS = ELEMENTWISE_MAX_OPS>
 __global__ __launch_bounds__(256) void k_elementwise(ElementwiseArgs<T> p) {
-    constexpr int U = 4;
+    constexpr int U = 4;   // (eight items per step on the four-statement instantiation: -8 %)
     const int c = int(blockIdx.x) * 256 + int(threadIdx.x);
     if (c >= p.n_comp) return;
     const T zero = T(0);
-    uint32_t op[ELEMENTWISE_MAX_OPS];
-    const T* ld_ptr[ELEMENTWISE_MAX_OPS];
-    int64_t ld_stride[ELEMENTWISE_MAX_OPS];
+    uint32_t op[NOPS];
+    const T* ld_ptr[NOPS];
+    int64_t ld_stride[NOPS];
 #pragma unroll
-    for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) {
+    for (int k = 0; k < NOPS; ++k) {
         const uint32_t w = k < p.n_ops ? p.ops[size_t(k) * p.n_comp + c] : 0u;
         op[k] = w & 3u;
         const int sl = int((w >> 2) & 7u);
@@ -461,12 +463,12 @@ __global__ __launch_bounds__(256) void k_elementwise(ElementwiseArgs<T> p) {
     const uint32_t oo = p.out_off ? p.out_off[c] : 0u;
     const T cf = p.out_off ? p.coeff[c] : zero;
     for (int64_t item0 = int64_t(blockIdx.y) * U; item0 < p.batch; item0 += int64_t(gridDim.y) * U) {
-        T x[U][ELEMENTWISE_MAX_OPS], v[U], s[U];
+        T x[U][NOPS], v[U], s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t item = item0 + u < p.batch ? item0 + u : item0;   // (the tail re-reads the step's first item; it is not stored twice)
 #pragma unroll
-            for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) x[u][k] = (op[k] & 1u) ? ld_ptr[k][item * ld_stride[k]] : zero;   // ops 1 and 3 read
+            for (int k = 0; k < NOPS; ++k) x[u][k] = (op[k] & 1u) ? ld_ptr[k][item * ld_stride[k]] : zero;   // ops 1 and 3 read
             v[u] = p.load_first ? p.res[item * p.res_stride + own] : zero;
             s[u] = p.out_off ? p.scalar[item * p.scalar_stride + p.scalar_off] : zero;
         }
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void k_elementwise(ElementwiseArgs<T> p) {
             if (item0 + u >= p.batch) break;
             T val = v[u];
 #pragma unroll
-            for (int k = 0; k < ELEMENTWISE_MAX_OPS; ++k) {
+            for (int k = 0; k < NOPS; ++k) {
                 if (op[k] == 2u) val = -val;                                       // graded.rs:63
                 else if (op[k]) val = (op[k] == 3u ? zero : val) + x[u][k];       // graded.rs:74 (op 3: onto the fresh +0.0 of init_null_mv)
             }

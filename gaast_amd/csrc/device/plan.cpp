@@ -2624,18 +2624,39 @@ static void fuse_elementwise_runs(Plan& plan) {
                 for (uint32_t w : t.u32_a) ops[(k - i) * nc + size_t(comp_of[w & 0xffffu])] = (t.beta ? 1u : 3u) | (slot << 2) | ((w >> 16) << 16);
             }
         }
+        // Every component executes ITS OWN statements in order, so each list is compacted on its own: empty statements go, and two
+        // sign flips in a row cancel exactly (-(-x) has the bits of x) -- (-(a.rev()) + b.ginvol()).rev() on grade-6 rows is
+        // copy, flip, flip, add, flip: three statements.  Four or fewer statements run on the kernel instantiation with half the
+        // registers (k_elementwise<T, 4>).
+        {
+            std::vector<std::vector<uint32_t>> lists(nc);
+            size_t longest = 1;
+            for (size_t c = 0; c < nc; ++c) {
+                for (size_t k = 0; k < n_ops; ++k) {
+                    const uint32_t w = ops[k * nc + c];
+                    if ((w & 3u) == 0u) continue;
+                    if ((w & 3u) == 2u && !lists[c].empty() && (lists[c].back() & 3u) == 2u) lists[c].pop_back();
+                    else lists[c].push_back(w);
+                }
+                longest = std::max(longest, lists[c].size());
+            }
+            ops.assign(longest * nc, 0u);
+            for (size_t c = 0; c < nc; ++c)
+                for (size_t k = 0; k < lists[c].size(); ++k) ops[k * nc + c] = lists[c][k];
+        }
+        const size_t n_stmt = ops.size() / nc;
         // does every component start with a copy (the run then never reads its buffer)?
         bool load_first = false;
         for (size_t c = 0; c < nc && !load_first; ++c) {
             size_t k = 0;
-            while (k < n_ops && ops[k * nc + c] == 0u) ++k;
-            load_first = k == n_ops || (ops[k * nc + c] & 3u) != 3u;
+            while (k < n_stmt && ops[k * nc + c] == 0u) ++k;
+            load_first = k == n_stmt || (ops[k * nc + c] & 3u) != 3u;
         }
         Step f;
         f.kind = Step::ELEMENTWISE;
         f.res = R;
         f.ew_src = srcs;
-        f.ew_ops = int(n_ops);
+        f.ew_ops = int(n_stmt);
         f.ew_load_first = load_first ? 1 : 0;
         f.u32_a = std::move(ops);
         f.u32_b = comps;

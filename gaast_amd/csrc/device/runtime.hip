@@ -420,7 +420,7 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
         return resident_blocks(s.kern[0], s.threads, s.lds, &s.blocks_per_cu);
     }
     case Step::ELEMENTWISE:
-        s.hip_kernel = "k_elementwise<" + tn + ">";
+        s.hip_kernel = "k_elementwise<" + tn + (s.ew_ops <= 4 ? ",4>" : ",8>");
         return GAAST_OK;
     case Step::AXPY: s.hip_kernel = "k_axpy_map<" + tn + ">"; return GAAST_OK;
     case Step::FLIP: s.hip_kernel = "k_flip<" + tn + ">"; return GAAST_OK;
@@ -935,7 +935,8 @@ int run_elementwise(const Step& s, const Bound& res, Resolve&& resolve, int64_t 
     const unsigned gx = unsigned((q.n_comp + 255) / 256);
     const int64_t want_y = std::max<int64_t>(1, int64_t(g_num_cu) * 16 / gx);
     const unsigned gy = unsigned(std::min<int64_t>(std::min<int64_t>((batch + 3) / 4, want_y), 65535));   // (a thread takes four items per step)
-    hipLaunchKernelGGL(k_elementwise<T>, dim3(gx, gy), dim3(256), 0, g_stream, q);
+    if (q.n_ops <= 4) hipLaunchKernelGGL((k_elementwise<T, 4>), dim3(gx, gy), dim3(256), 0, g_stream, q);
+    else hipLaunchKernelGGL((k_elementwise<T, ELEMENTWISE_MAX_OPS>), dim3(gx, gy), dim3(256), 0, g_stream, q);
     HIP_TRY(hipGetLastError());
     return GAAST_OK;
 }

@@ -20,7 +20,7 @@ HIP_KERNEL = {"r12": "k_gp_mfma32p", "r8": "k_gp_mfma16x4<float>", "cl41": "gaas
               "sand9g1x": "gaast_chain (hiprtc), reference order", "sand8g1": "gaast_chain (hiprtc)", "sand10g1": "gaast_chain (hiprtc)",
               "gp6f32": "k_gp_mfma6<float,false,true>", "gp6f64": "k_gp_mfma6<double,false,true>", "cl41s": "gaast_jit",
               "vinv8": "gaast_jit (slabs in LDS)", "proj12": "gaast_jit (slabs in LDS)", "vinv12": "k_reduce_scale<double>",
-              "cfg1_8": "gaast_chain (hiprtc), one list", "cfg1_12": "gaast_chain (hiprtc), one list", "unary12": "k_elementwise<double>"}
+              "cfg1_8": "gaast_chain (hiprtc), one list", "cfg1_12": "gaast_chain (hiprtc), one list", "unary12": "k_elementwise<double,4>"}
 
 
 def main():
