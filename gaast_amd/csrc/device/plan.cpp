@@ -1959,6 +1959,28 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     else { off_l1 = place(l1); off_r1 = place(r1); }
     off_neg = place(neg_len);
     off_mid = place(mid);
+    // tolerance mode: list 2 sign-sorted (below) -- when the item still fits the 16-bit byte offsets with one more element, and the
+    // rows' signs are balanced enough: every (row, slice) pair is padded to the longest plus and the longest minus segment, and a
+    // padding term costs what a real one does (Euclidean sandwiches at n = 8, 10 have all-plus rows: +50 % terms -- they keep the
+    // sign words; R^{6,3} at n = 9: 64 + 64 of 128, no padding; (a + b c).g(2) at n = 8: 136 + 136 for 256)
+    bool sorted = !(plan.flags & GAAST_FLAG_EXACT_ORDER) && (cur + 1) * esz <= 65536;
+    if (sorted) {
+        const int64_t rows2e = int64_t(c.u32_b.size()), w2e = c.ell_width;
+        int64_t sp = 1;   // (the slice count of the tolerance mode, decided again below with the same rule)
+        while (sp < 4 && w2e % (2 * sp) == 0 && w2e / (2 * sp) >= 32 && rows2e * 32 * 2 * sp <= 1024 && rows2e * 2 * sp <= mid) sp *= 2;
+        const int64_t gran = plan.dtype == GAAST_F32 ? 16 : 8;
+        int64_t wp = 0, wm = 0;
+        for (int64_t row = 0; row < rows2e; ++row) {
+            int64_t np = 0, nm = 0;
+            for (int64_t t = 0; t < w2e; ++t) ((c.u32_c[size_t(t * rows2e + row)] & 0x80000000u) ? nm : np) += 1;
+            wp = std::max(wp, (np + sp - 1) / sp);
+            wm = std::max(wm, (nm + sp - 1) / sp);
+        }
+        wp = (wp + gran - 1) / gran * gran;
+        wm = (wm + gran - 1) / gran * gran;
+        sorted = rows2e > 0 && w2e > 0 && (wp + wm) * sp * 100 <= w2e * 107;
+    }
+    const int64_t off_zero = sorted ? place(1) : 0;               // ... its padding terms multiply this element by itself
     int64_t stride = cur | 1;   // odd: lanes reading one offset of consecutive items touch consecutive banks (bank pairs in f64)
     const int64_t off_other = alias == 0 ? off_r2 : alias == 1 ? off_l1 : off_r1;
     const int64_t other_len = alias == 0 ? r2 : alias == 1 ? l1 : r1;
@@ -1980,8 +2002,41 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     //   list 1: rows padded to quads (16-byte reads) when that fits, else unpadded rows (4-byte reads), else global memory.
     const int64_t items_bytes = (ipb * stride * esz + 15) / 16 * 16;
     int64_t used = items_bytes;
-    int ent2_mode;   // 0: narrow, global; 1: narrow, LDS; 2: wide, LDS
-    if (used + rows2 * w2p * 8 <= lds_cap) ent2_mode = 2, used += rows2 * w2p * 8;
+    // TOLERANCE MODE, SIGN-SORTED (round 4): the order inside a row is free, so the terms of every (row, slice) pair are stored
+    // plus-terms first (padded to WPS), then minus-terms (padded to WMS): the sign is the POSITION -- no sign word, no sign
+    // instruction: a term is two SDWA address additions and one fused multiply-add (exact order: 5, narrow entries: 7) -- and the
+    // entries are clean 16 + 16-bit words (half the wide table: at n = 9 list 1's table then fits in LDS too).  Padding terms
+    // multiply the item's zero element by itself.  The slice count is decided first (it shapes the table).
+    int64_t split = 1;
+    if (!(plan.flags & GAAST_FLAG_EXACT_ORDER))
+        while (split < 4 && w2 % (2 * split) == 0 && w2 / (2 * split) >= 32 && rows2 * ipb * 2 * split <= 1024 && rows2 * 2 * split <= mid) split *= 2;
+    int64_t wps = 0, wms = 0;   // plus / minus terms per (row, slice), multiples of 8 (f32: 16): whole register batches
+    std::vector<std::vector<uint32_t>> plus_terms, minus_terms;   // per row: mid offset | other offset << 16 (bytes)
+    if (sorted) {
+        plus_terms.resize(size_t(rows2));
+        minus_terms.resize(size_t(rows2));
+        const int64_t off_other_b = (alias == 0 ? off_r2 : alias == 1 ? off_l1 : off_r1) * esz;
+        for (int64_t row = 0; row < rows2; ++row)
+            for (int64_t t = 0; t < w2; ++t) {
+                const uint32_t e = c.u32_c[size_t(t * rows2 + row)];
+                const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;
+                const int64_t ma = off_mid * esz + (side == 1 ? lo : ro), oa = off_other_b + (side == 1 ? ro : lo);
+                ((e & 0x80000000u) ? minus_terms : plus_terms)[size_t(row)].push_back(uint32_t(ma) | (uint32_t(oa) << 16));
+            }
+        const int64_t gran = plan.dtype == GAAST_F32 ? 16 : 8;
+        for (int64_t row = 0; row < rows2; ++row) {
+            wps = std::max<int64_t>(wps, (int64_t(plus_terms[size_t(row)].size()) + split - 1) / split);
+            wms = std::max<int64_t>(wms, (int64_t(minus_terms[size_t(row)].size()) + split - 1) / split);
+        }
+        wps = (wps + gran - 1) / gran * gran;
+        wms = (wms + gran - 1) / gran * gran;
+    }
+    const int64_t wss = wps + wms;
+    int ent2_mode;   // 0: narrow, global; 1: narrow, LDS; 2: wide, LDS; sorted: 3: LDS, 4: global
+    if (sorted) {
+        if (used + rows2 * split * wss * 4 <= lds_cap) ent2_mode = 3, used += rows2 * split * wss * 4;
+        else ent2_mode = 4;
+    } else if (used + rows2 * w2p * 8 <= lds_cap) ent2_mode = 2, used += rows2 * w2p * 8;
     else if (used + rows2 * w2p * 4 <= lds_cap) ent2_mode = 1, used += rows2 * w2p * 4;
     else ent2_mode = 0;
     const int64_t ent2_at = items_bytes;
@@ -1995,9 +2050,6 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     // consecutive terms, each summed by a lane of its own in the reference's order, the partial sums added in slice order at the end --
     // the few long chains that leave most of the workgroup idle become split x as many, half as long.  |error| <= 4 eps sum |terms|
     // per component (the dense path's contract; one extra rounding per slice).  GAAST_FLAG_EXACT_ORDER: split = 1, bit for bit.
-    int64_t split = 1;
-    if (!(plan.flags & GAAST_FLAG_EXACT_ORDER))
-        while (split < 4 && w2 % (2 * split) == 0 && w2 / (2 * split) >= 32 && rows2 * ipb * 2 * split <= 1024 && rows2 * 2 * split <= mid) split *= 2;
     // one workgroup per CU (the usual case from n = 9 on): 512 threads -- list 1 and the staging have work for all of them, list 2
     // (few long rows) for rows2 * split * ipb lanes; two or more workgroups per CU: 256 threads each
     int64_t threads = 2 * used <= lds_cap ? 256 : 512;
@@ -2023,9 +2075,22 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
         }
     }
     const int64_t wpt2 = ent2_mode == 2 ? 2 : 1;   // words per term
-    c.cj_ent2.assign(size_t(rows2 * w2p * wpt2), 0u);
     c.cj_out2 = c.u32_b;
-    for (int64_t row = 0; row < rows2; ++row)
+    if (sorted) {
+        const uint32_t pad = uint32_t(off_zero * esz) | (uint32_t(off_zero * esz) << 16);
+        c.cj_ent2.assign(size_t(rows2 * split * wss), pad);
+        for (int64_t row = 0; row < rows2; ++row)
+            for (int which = 0; which < 2; ++which) {
+                const std::vector<uint32_t>& tv = which ? minus_terms[size_t(row)] : plus_terms[size_t(row)];
+                const int64_t per = (int64_t(tv.size()) + split - 1) / split;   // consecutive chunks, one per slice
+                for (int64_t i = 0; i < int64_t(tv.size()); ++i) {
+                    const int64_t sl = per ? i / per : 0, k = per ? i % per : 0;
+                    c.cj_ent2[size_t((row * split + sl) * wss + (which ? wps : 0) + k)] = tv[size_t(i)];
+                }
+            }
+    } else
+        c.cj_ent2.assign(size_t(rows2 * w2p * wpt2), 0u);
+    for (int64_t row = 0; row < rows2 && !sorted; ++row)
         for (int64_t t = 0; t < w2; ++t) {
             const uint32_t e = c.u32_c[size_t(t * rows2 + row)];
             const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;
@@ -2055,6 +2120,7 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     // EXACT: every product rounded, then added (eval.rs:82), rows summed whole -- the reference's bits.  Otherwise (the default,
     // the dense products' tolerance contract): rows of list 2 in slices, and l * r + acc as one fused multiply-add
     def("EXACT", (plan.flags & GAAST_FLAG_EXACT_ORDER) ? 1 : 0);
+    def("SORTED", sorted ? 1 : 0); def("WPS", wps); def("WMS", wms); def("WSS", wss); def("OFF_ZERO", off_zero * esz);
     def("SPLIT", split); def("WS", w2 / split);                    // slices per row of list 2, terms per slice
     def("PASSES2", (rows2 * split + threads / ipb - 1) / (threads / ipb));   // (row, slice) pairs of list 2 per thread
     // terms of list 2 in flight per register set: the registers of two waves per SIMD (512 threads) hold 8 f64 / 16 f32 terms twice; more
@@ -2141,7 +2207,12 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     u32 one_hi = ONE_HI;
     asm volatile("" : "+v"(one_hi));   // a vector register (the and-or takes one scalar operand)
     // the tables, once per (persistent) workgroup
-#if ENT2_MODE == 2
+#if SORTED
+    for (int e = tid; e < IPB; e += NT) *(__attribute__((address_space(3))) T*)(smem + e * STRIDE_B + OFF_ZERO) = T(0);   // the padding terms' operand
+#endif
+#if ENT2_MODE == 3
+    for (int e = tid; e < ROWS2 * SPLIT * WSS / 4; e += NT) ((__attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[e] = ((const u32x4*)ent2)[e];
+#elif ENT2_MODE == 2
     for (int e = tid; e < ROWS2 * W2P / 2; e += NT) ((__attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[e] = ((const u32x4*)ent2)[e];
 #elif ENT2_MODE == 1
     for (int e = tid; e < ROWS2 * W2P / 4; e += NT) ((__attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[e] = ((const u32x4*)ent2)[e];
@@ -2330,6 +2401,48 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
 #else
             T acc = T(0);                                // (slices start from zero: what the row adds onto joins them at the end)
 #endif
+#if SORTED
+            // tolerance mode, sign-sorted: WPS plus-terms, then WMS minus-terms (both whole batches of TB; the padding multiplies the item's
+            // zero element by itself): no sign per term -- two address additions and one fused multiply-add
+            {
+                T ma[TB], oa[TB], mb[TB], ob[TB];
+                auto load2 = [&](T (&mv)[TB], T (&ov)[TB], int q) {      // TB terms from quad q of this (row, slice)
+#pragma unroll
+                    for (int i = 0; i < TB / 4; ++i) {
+#if ENT2_MODE == 3
+                        const u32x4 e4 = ((const __attribute__((address_space(3))) u32x4*)(smem + ENT2_AT))[vrow * (WSS / 4) + q + i];
+#else
+                        const u32x4 e4 = ((const u32x4*)ent2)[vrow * (WSS / 4) + q + i];
+#endif
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            mv[4 * i + j] = LDS(base + (e4[j] & 0xffffu));
+                            ov[4 * i + j] = LDS(base + (e4[j] >> 16));
+                        }
+                    }
+                };
+                constexpr int NBT = WSS / TB, NBP = WPS / TB;            // batches in all, plus-batches first
+                auto sum2 = [&](const T (&mv)[TB], const T (&ov)[TB], int b) {
+                    if (b < NBP) {
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) acc = FMA(mv[t], ov[t], acc);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) acc = FMA(-mv[t], ov[t], acc);
+                    }
+                };
+                load2(ma, oa, 0);
+                int b = 0;
+#pragma nounroll
+                for (; b + 2 <= NBT; b += 2) {
+                    load2(mb, ob, (b + 1) * (TB / 4));
+                    sum2(ma, oa, b);
+                    load2(ma, oa, (b + 2 < NBT ? b + 2 : NBT - 1) * (TB / 4));
+                    sum2(mb, ob, b + 1);
+                }
+                if (NBT & 1) sum2(ma, oa, NBT - 1);
+            }
+#else
             constexpr int NB = WS / TB;                  // batches of TB terms
             constexpr int QPT = ENT2_MODE == 2 ? 2 : 4;  // terms per table quad
             const int q0 = slice * (WS / QPT);           // the slice's first quad (WS is a multiple of 4)
@@ -2407,6 +2520,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
                 acc = FMA(LDS(base + (e & 0xffffu)) * LDS(base + ((e >> 16) & 0x7fffu)), pm_one((e & 0x80000000u) | ONE_HI), acc);
 #endif
             }
+#endif
 #if SPLIT > 1
             part[pass] = acc;
 #else
@@ -2451,6 +2565,9 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     for (int i = 0; i < 7; ++i) c.cj_layout[i] = int(lay[i]);
     c.cj_fmt[0] = int(w1s);
     c.cj_fmt[1] = ent2_mode;
+    c.cj_sorted[0] = int(wps);
+    c.cj_sorted[1] = int(wms);
+    c.cj_sorted[2] = int(off_zero * esz);
     c.cj_split = int(split);
     c.cj_ipb = int(ipb);
     c.cj_threads = int(threads);

@@ -122,7 +122,8 @@ struct Step {
     int cj_ipb = 0, cj_threads = 0;
     size_t cj_lds = 0;
     int cj_split = 1;                            // slices per row of list 2 (> 1: re-ordered sums, tolerance mode; 1 with GAAST_FLAG_EXACT_ORDER)
-    int cj_fmt[2] = {0, 0};                     // words per row of list 1's table; list 2's entries: 2 = wide (8 bytes: offsets, then the sign bit), else narrow
+    int cj_sorted[3] = {0, 0, 0};               // tolerance mode, sign-sorted list 2: plus / minus terms per (row, slice), byte offset of the item's zero element
+    int cj_fmt[2] = {0, 0};                     // words per row of list 1's table; list 2's entries: 2 = wide (8 bytes: offsets, then the sign bit), 3 / 4 = sign-sorted clean words (LDS / global), else narrow
     int cj_layout[7] = {0, 0, 0, 0, 0, 0, 0};   // an item in LDS, elements: offsets of l1, r1, the negated image, mid, r2 (-1: aliased); item stride; negated image is of the left operand
     int use_mfma = 0;
     int use_mfma16 = 0;  // k_gp_mfma16x4<T> (lo = 4 bits, one item per workgroup): f64 n = 8 ... 12, f32 n = 8, 9

@@ -229,7 +229,8 @@ int prepare_step(Step& s, const Layout& la, const Layout& lb, int n) {
             s.threads = s.cj_threads;
             s.lds = s.cj_lds;
             s.hip_kernel = "gaast_chain<" + tn + ">[" + (s.list_jit ? "one list, " : "") + std::to_string(s.cj_ipb) + " items, " + std::to_string(s.cj_threads) + " threads" +
-                           (s.cj_split > 1 ? ", rows in " + std::to_string(s.cj_split) + " slices: re-ordered sums" : "") + "]";
+                           (s.cj_split > 1 ? ", rows in " + std::to_string(s.cj_split) + " slices: re-ordered sums" : "") +
+                           (s.cj_fmt[1] >= 3 ? ", sign-sorted terms" : "") + "]";
             int per_cu = 0;
             HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, static_cast<hipFunction_t>(s.jit_function), s.threads, 0));
             s.blocks_per_cu = per_cu < 1 ? 1 : per_cu;

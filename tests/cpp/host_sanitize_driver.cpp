@@ -2,6 +2,7 @@
 // through the C host API of include/gaast_expr.h, lowered with gaast::build_plan (the launch plan and
 // every table the kernels index), serialized and deserialized.  Any out-of-bounds table write or
 // undefined shift in the bitmask arithmetic aborts the run.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -232,14 +233,16 @@ static void dense_tables_agree_with_the_list(int n, const double* metric, int dt
 // (byte offsets from the item's base in a new LDS layout, list 1's signs folded into a negated image).  Both table sets are
 // executed here, in plain C++ doubles in the kernels' order, on the same random rows: every result bit must agree.  With a
 // directory argument the generated kernel source is written there (tests/test_chain_jit.py compiles it for gfx950).
-static void chain_tables_agree(int n, const double* metric, int dtype, const char* dump_dir) {
+// (flags = GAAST_FLAG_EXACT_ORDER: the tables of the reference order, compared bit for bit; 0: the tolerance mode's sign-sorted table of
+//  list 2 -- plus terms, then minus terms, per (row, slice) -- summed in ITS order and compared within 1e-12)
+static void chain_tables_agree(int n, const double* metric, int dtype, const char* dump_dir, uint32_t flags = GAAST_FLAG_EXACT_ORDER) {
     gaast_expr_t r = gaast_expr_input(0, 0x5555555555555555ull & full_mask(n), n), x = gaast_expr_input(1, 0x2, n);
     gaast_expr_t e = gaast_expr_g(gaast_expr_product(gaast_expr_product(r, x, GAAST_PROD_GEOMETRIC), gaast_expr_rev(r), GAAST_PROD_GEOMETRIC), 1);
     gaast_spec_t spec = gaast_expr_specialize(e, n, metric, 1 << 16);
     CHECK(spec != nullptr);
     if (!spec) return;
     gaast_program_desc desc;
-    CHECK(gaast_spec_program_desc(spec, dtype, 0, &desc) == 0);
+    CHECK(gaast_spec_program_desc(spec, dtype, flags, &desc) == 0);
     gaast::Plan plan;
     gaast::build_plan(desc, plan);
     CHECK(plan.steps.size() == 1 && plan.steps[0].list_chain && plan.steps[0].chain_jit == 1);
@@ -260,7 +263,13 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
     const int l1 = s.pre_left_len, r1 = s.pre_right_len, mid = s.chain_mid_len;
     const int rows1 = int(s.pre_row_map.size()), w1 = s.pre_width, rows2 = int(s.u32_b.size()), w2 = s.ell_width;
     const int w1p = s.cj_fmt[0], w2p = (w2 + 3) & ~3, wide = s.cj_fmt[1] == 2 ? 2 : 1;
-    CHECK(int(s.cj_ent1.size()) == rows1 * w1p && int(s.cj_ent2.size()) == rows2 * w2p * wide && s.chain_alias == 1 && s.list_chain == 1);
+    const bool sorted = s.cj_fmt[1] >= 3;
+    // (sign-sorted only without the flag, and only when the rows' signs are balanced: R^{6,3} at n = 9 is, the Euclidean n = 8, 10 are not)
+    CHECK(!sorted || !(flags & GAAST_FLAG_EXACT_ORDER));
+    if (!(flags & GAAST_FLAG_EXACT_ORDER) && n == 9) CHECK(sorted);
+    const int wss = s.cj_sorted[0] + s.cj_sorted[1];
+    CHECK(int(s.cj_ent1.size()) == rows1 * w1p && s.chain_alias == 1 && s.list_chain == 1);
+    CHECK(int(s.cj_ent2.size()) == (sorted ? rows2 * s.cj_split * wss : rows2 * w2p * wide));
     std::vector<double> L(static_cast<size_t>(l1), 0.0), X(static_cast<size_t>(r1), 0.0);
     unsigned long long seed = 88172645463325252ull + unsigned(n);
     auto rnd = [&]() {
@@ -308,7 +317,26 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
         at(s.cj_pos1[size_t(row)]) = acc;
     }
     bool same = true;
-    for (int row = 0; row < rows2; ++row) {
+    for (int row = 0; row < rows2 && sorted; ++row) {   // slices in order, each plus terms then minus terms; every real term exactly once
+        double acc = 0.0, mag = 0.0;
+        int real_terms = 0;
+        for (int sl = 0; sl < s.cj_split; ++sl) {
+            double part = 0.0;
+            for (int t = 0; t < wss; ++t) {
+                const uint32_t w = s.cj_ent2[(size_t(row) * s.cj_split + sl) * wss + t];
+                const bool pad = (w & 0xffffu) == uint32_t(s.cj_sorted[2]) && (w >> 16) == uint32_t(s.cj_sorted[2]);
+                const double pr = at(w & 0xffffu) * at(w >> 16);
+                part = t < s.cj_sorted[0] ? part + pr : part - pr;
+                mag += std::fabs(pr);
+                real_terms += pad ? 0 : 1;
+                CHECK(!pad || pr == 0.0);
+            }
+            acc = acc + part;
+        }
+        CHECK(real_terms == w2);
+        same = same && std::fabs(acc - out_a[size_t(row)]) <= 1e-12 * (mag + 1.0) && s.cj_out2[size_t(row)] == s.u32_b[size_t(row)];
+    }
+    for (int row = 0; row < rows2 && !sorted; ++row) {
         double acc = 0.0;
         for (int t = 0; t < w2; ++t) {
             const uint32_t w = s.cj_ent2[(size_t(row) * w2p + t) * wide];
@@ -326,7 +354,7 @@ static void chain_tables_agree(int n, const double* metric, int dtype, const cha
 
 // ... and a SINGLE list with few long rows on the same kernel (plan.cpp: jit_long_row_lists): d = (a + b * c).g(2), the covering copy of
 // a's grade 2 folded into the list's accumulators.  Generic ELL words against the specialised tables, bit for bit.
-static void single_list_tables_agree(int n, int dtype, const char* dump_dir) {
+static void single_list_tables_agree(int n, int dtype, const char* dump_dir, uint32_t flags = GAAST_FLAG_EXACT_ORDER) {
     std::vector<double> metric(size_t(n), 1.0);
     gaast_expr_t a = gaast_expr_input(0, full_mask(n), n), b = gaast_expr_input(1, full_mask(n), n), c = gaast_expr_input(2, full_mask(n), n);
     gaast_expr_t e = gaast_expr_g(gaast_expr_add(a, gaast_expr_product(b, c, GAAST_PROD_GEOMETRIC)), 2);
@@ -334,7 +362,7 @@ static void single_list_tables_agree(int n, int dtype, const char* dump_dir) {
     CHECK(spec != nullptr);
     if (!spec) return;
     gaast_program_desc desc;
-    CHECK(gaast_spec_program_desc(spec, dtype, 0, &desc) == 0);
+    CHECK(gaast_spec_program_desc(spec, dtype, flags, &desc) == 0);
     gaast::Plan plan;
     gaast::build_plan(desc, plan);
     CHECK(plan.steps.size() == 2 && plan.steps[0].kind == gaast::Step::AXPY && plan.steps[0].beta == 0 && plan.steps[1].list_jit == 1 &&
@@ -383,7 +411,33 @@ static void single_list_tables_agree(int n, int dtype, const char* dump_dir) {
     for (int c2 = 0; c2 < N; ++c2) img[size_t(lay[3] + c2)] = B[size_t(c2)];
     for (int c2 = 0; c2 < N; ++c2) img[size_t(lay[4] + c2)] = Cc[size_t(c2)];
     bool same = int(s.cj_pos1.size()) == rows;
-    for (int row = 0; row < rows && same; ++row) {
+    const bool sorted = s.cj_fmt[1] >= 3;
+    CHECK(!sorted || !(flags & GAAST_FLAG_EXACT_ORDER));
+    if (!(flags & GAAST_FLAG_EXACT_ORDER) && n == 8 && dtype == GAAST_F64) CHECK(sorted);   // 136 + 136 terms for 256
+    if (n == 12) CHECK(!sorted);                                                              // 2 x 32 KiB of operands leave no room for the zero element
+    const int wss = s.cj_sorted[0] + s.cj_sorted[1];
+    for (int row = 0; row < rows && same && sorted; ++row) {
+        double acc = 0.0 + A[s.cj_pos1[size_t(row)]], mag = 1.0;
+        int real_terms = 0;
+        for (int sl = 0; sl < s.cj_split; ++sl) {
+            double part = 0.0;
+            for (int t = 0; t < wss; ++t) {
+                const uint32_t w = s.cj_ent2[(size_t(row) * s.cj_split + sl) * wss + t];
+                const uint32_t mo = w & 0xffffu, oo = w >> 16;
+                CHECK(mo % esz == 0 && oo % esz == 0 && mo / esz < uint32_t(lay[5]) && oo / esz < uint32_t(lay[5]));
+                const bool pad = mo == uint32_t(s.cj_sorted[2]) && oo == uint32_t(s.cj_sorted[2]);
+                const double pr = img[mo / esz] * img[oo / esz];
+                part = t < s.cj_sorted[0] ? part + pr : part - pr;
+                mag += std::fabs(pr);
+                real_terms += pad ? 0 : 1;
+                CHECK(!pad || pr == 0.0);
+            }
+            acc = acc + part;
+        }
+        CHECK(real_terms == w2);
+        same = std::fabs(acc - out_a[s.cj_out2[size_t(row)]]) <= 1e-12 * mag;
+    }
+    for (int row = 0; row < rows && same && !sorted; ++row) {
         double acc = 0.0 + A[s.cj_pos1[size_t(row)]];
         for (int t = 0; t < w2; ++t) {
             const uint32_t w = s.cj_ent2[(size_t(row) * w2p + t) * wide];
@@ -406,6 +460,9 @@ int main(int argc, char** argv) {
     single_list_tables_agree(8, GAAST_F32, dump_dir);
     single_list_tables_agree(9, GAAST_F64, dump_dir);
     single_list_tables_agree(12, GAAST_F64, dump_dir);
+    single_list_tables_agree(8, GAAST_F64, dump_dir, 0);    // tolerance mode: the sign-sorted table
+    single_list_tables_agree(8, GAAST_F32, dump_dir, 0);
+    single_list_tables_agree(12, GAAST_F64, dump_dir, 0);
     {
         const double euclid16[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         const double mixed9[9] = {1, 1, 1, 1, 1, 1, -1, -1, -1};
@@ -414,6 +471,10 @@ int main(int argc, char** argv) {
         chain_tables_agree(10, euclid16, GAAST_F64, dump_dir);
         chain_tables_agree(9, mixed9, GAAST_F32, dump_dir);
         chain_tables_agree(12, euclid16, GAAST_F64, dump_dir);
+        chain_tables_agree(8, euclid16, GAAST_F64, dump_dir, 0);    // tolerance mode: the sign-sorted table of list 2
+        chain_tables_agree(9, mixed9, GAAST_F64, dump_dir, 0);
+        chain_tables_agree(10, euclid16, GAAST_F64, dump_dir, 0);
+        chain_tables_agree(9, mixed9, GAAST_F32, dump_dir, 0);
     }
     const double euclid[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     const double cga[5] = {1, 1, 1, 1, -1};

@@ -542,6 +542,11 @@ def test_projected_rotor_sandwich_is_one_launch_of_two_lists(n, metric):
     assert tmask == wmask and len(spec4.launches()) == 1 and "gaast_chain<double>" in spec4.launches()[0], spec4.launches()
     if n <= 10:
         assert "re-ordered sums" in spec4.launches()[0], spec4.launches()
+    # (round 4: when the rows' signs are balanced -- R^{6,3} at n = 9: 64 plus and 64 minus terms per slice -- list 2's terms are
+    #  stored plus-first: the sign is the position, a term is two address additions and one fused multiply-add; the Euclidean n = 8, 10
+    #  have all-plus rows and keep their sign words)
+    if n <= 10:
+        assert ("sign-sorted terms" in spec4.launches()[0]) == (n == 9), spec4.launches()
     mid, mmask = oracle_eval_batch(lambda B: B.input(0, even, n) * B.input(1, [1], n), alg, rows, batch)
     odd = [k for k in range(n + 1) if (mmask >> k) & 1]
     for i in range(batch):
