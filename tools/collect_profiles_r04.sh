@@ -66,6 +66,7 @@ pmc2)
   pmc unary12 k_elementwise --workload unary12
   pmc cl41 gaast_jit --workload cl41
   pmc r8 k_gp_mfma16 --workload r8
+  pmc r12d k_gp_mfma16x4 --workload r12d
   ;;
 pmc3)
   pmc sand8 k_gp_mfma7 --workload sand8
