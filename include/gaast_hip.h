@@ -151,6 +151,7 @@ typedef struct gaast_input_desc {
 #define GAAST_FLAG_EXP_LOG 0x100u
 #define GAAST_FLAG_DEBUG_LDS_12K 0x400u /* hiprtc-specialised kernels: 12 KiB instead of 10 KiB of LDS per wave for the row transposition (A/B testing) */
 #define GAAST_FLAG_DEBUG_NO_CHAIN 0x800u /* a sparse product that only feeds a dense product stays a launch of its own (default: evaluated in the dense kernel's LDS staging; A/B testing) */
+/* (bits 30 and 31 are reserved for the library's own use: a plan rebuilt after a trial compilation carries one) */
 #define GAAST_FLAG_DEBUG_FAIL_EVAL 0x1000u /* every evaluation of this program fails with GAAST_ERR_HIP before its first launch: exercises the failure path of gaast_hip_eval_gather on ONE rank */
 #define GAAST_FLAG_NO_COALESCE 0x200u  /* hiprtc-specialised kernels: every lane reads / writes its own row (no LDS-transposed coalesced row I/O; A/B testing) */
 
