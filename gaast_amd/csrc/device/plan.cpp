@@ -1980,7 +1980,8 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
         wm = (wm + gran - 1) / gran * gran;
         sorted = rows2e > 0 && w2e > 0 && (wp + wm) * sp * 100 <= w2e * 107;
     }
-    const int64_t off_zero = sorted ? place(1) : 0;               // ... its padding terms multiply this element by itself
+    const bool has_zero = !(plan.flags & GAAST_FLAG_EXACT_ORDER) && (cur + 1) * esz <= 65536;
+    const int64_t off_zero = has_zero ? place(1) : 0;             // ... padding terms (sorted list 2, list 1 by right index) multiply this element
     int64_t stride = cur | 1;   // odd: lanes reading one offset of consecutive items touch consecutive banks (bank pairs in f64)
     const int64_t off_other = alias == 0 ? off_r2 : alias == 1 ? off_l1 : off_r1;
     const int64_t other_len = alias == 0 ? r2 : alias == 1 ? l1 : r1;
@@ -2060,6 +2061,18 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     threads = std::min<int64_t>(1024, (threads + 255) / 256 * 256);
     const int64_t w1s = ent1_mode == 1 ? w1 : w1p;   // words per row of list 1's table
     // tables
+    // TOLERANCE MODE, list 1 with its small right operand IN REGISTERS (the sandwich's X: n components, the same for every row a lane
+    // evaluates): the terms of a row are re-ordered by right index -- term j multiplies by x_j, a register --, so a term is ONE LDS
+    // read (the left operand), its sign a bit of the table word; rows without a term for some j multiply the item's zero element.
+    bool xreg = has_zero && !single && !neg_is_left && r1 <= 12 && w1 <= r1 && ent1_mode != 1 && w1s >= ((r1 + 3) & ~int64_t(3));
+    for (int64_t row = 0; row < rows1 && xreg; ++row) {
+        uint32_t seen = 0;
+        for (int64_t t = 0; t < w1 && xreg; ++t) {
+            const int64_t j = int64_t((w.u32_c[size_t(t * rows1 + row)] >> 16) & 0x7fffu) / esz;
+            xreg = j < r1 && !(seen & (1u << j));
+            seen |= 1u << j;
+        }
+    }
     c.cj_ent1.assign(size_t(rows1 * w1s), 0u);
     c.cj_pos1.resize(size_t(rows1));
     if (init_off) c.cj_pos1 = *init_off;   // (a single list has no row positions: the slot carries the offsets of the folded copy)
@@ -2071,7 +2084,15 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
             const int64_t lo = e & 0x7fffu, ro = (e >> 16) & 0x7fffu;   // bytes, from the operand rows
             const int64_t la = ((neg && neg_is_left) ? off_neg : off_l1) * esz + lo;
             const int64_t ra = ((neg && !neg_is_left) ? off_neg : off_r1) * esz + ro;
-            c.cj_ent1[size_t(row * w1s + t)] = uint32_t(la) | (uint32_t(ra) << 16);
+            if (!xreg) c.cj_ent1[size_t(row * w1s + t)] = uint32_t(la) | (uint32_t(ra) << 16);
+        }
+        if (xreg) {
+            for (int64_t j = 0; j < w1s; ++j) c.cj_ent1[size_t(row * w1s + j)] = uint32_t(off_zero * esz);   // no term for x_j: 0 * x_j
+            for (int64_t t = 0; t < w1; ++t) {
+                const uint32_t e = w.u32_c[size_t(t * rows1 + row)];
+                const int64_t lo = e & 0x7fffu, j = int64_t((e >> 16) & 0x7fffu) / esz;
+                c.cj_ent1[size_t(row * w1s + j)] = uint32_t(off_l1 * esz + lo) | (e & 0x80000000u);
+            }
         }
     }
     const int64_t wpt2 = ent2_mode == 2 ? 2 : 1;   // words per term
@@ -2120,6 +2141,7 @@ static void make_chain_jit(const Plan& plan, Step& c, const Step* wp, int64_t l1
     // EXACT: every product rounded, then added (eval.rs:82), rows summed whole -- the reference's bits.  Otherwise (the default,
     // the dense products' tolerance contract): rows of list 2 in slices, and l * r + acc as one fused multiply-add
     def("EXACT", (plan.flags & GAAST_FLAG_EXACT_ORDER) ? 1 : 0);
+    def("XREG", xreg ? 1 : 0);
     def("SORTED", sorted ? 1 : 0); def("WPS", wps); def("WMS", wms); def("WSS", wss); def("OFF_ZERO", off_zero * esz);
     def("SPLIT", split); def("WS", w2 / split);                    // slices per row of list 2, terms per slice
     def("PASSES2", (rows2 * split + threads / ipb - 1) / (threads / ipb));   // (row, slice) pairs of list 2 per thread
@@ -2207,7 +2229,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     u32 one_hi = ONE_HI;
     asm volatile("" : "+v"(one_hi));   // a vector register (the and-or takes one scalar operand)
     // the tables, once per (persistent) workgroup
-#if SORTED
+#if SORTED || XREG
     for (int e = tid; e < IPB; e += NT) *(__attribute__((address_space(3))) T*)(smem + e * STRIDE_B + OFF_ZERO) = T(0);   // the padding terms' operand
 #endif
 #if ENT2_MODE == 3
@@ -2348,6 +2370,49 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
         // ---- list 1 -> mid (eval.rs:77-83 into the fresh cache buffer of eval.rs:21-33): the operands of row k + 1 are in
         // flight while row k's chain is evaluated (two register sets, the loop unrolled by two: no copies) ----
 #if !SINGLE
+#if XREG
+        {   // list 1 with the right operand (R1 components of THIS lane's item) in registers: term j of every row multiplies by xr[j]
+            T xr[R1];
+#pragma unroll
+            for (int j = 0; j < R1; ++j) xr[j] = LDS(base + OFF_R1 + j * ESZ);
+            T la[R1], lb[R1];
+            u32 ea[R1], eb[R1];
+            auto load1 = [&](T (&lv)[R1], u32 (&ev)[R1], int row) {
+#pragma unroll
+                for (int q = 0; q < (R1 + 3) / 4; ++q) {
+                    const u32x4 e4 = ent1_quad(row, q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j < R1) {
+                            lv[4 * q + j] = LDS(base + (e4[j] & 0xffffu));
+                            ev[4 * q + j] = e4[j];
+                        }
+                }
+            };
+            auto sum1 = [&](const T (&lv)[R1], const u32 (&ev)[R1], int row) {
+                T acc = T(0);
+#pragma unroll
+                for (int t = 0; t < R1; ++t) acc = FMA(with_hi(lv[t], hi_of(lv[t]) ^ (ev[t] & 0x80000000u)), xr[t], acc);
+#if POS1_LINEAR
+                *(__attribute__((address_space(3))) T*)(smem + base + OFF_MID + row * ESZ) = CANON_MID ? T(0) + acc : acc;
+#else
+                *(__attribute__((address_space(3))) T*)(smem + base + pos1[row]) = CANON_MID ? T(0) + acc : acc;
+#endif
+            };
+            constexpr int LAST1 = ROWS1 - 1;
+            int row = sub;
+            if (row < ROWS1) load1(la, ea, row);
+#pragma nounroll
+            for (; row < ROWS1; row += 2 * NSUB) {
+                const int r2_ = row + NSUB, r3_ = row + 2 * NSUB;
+                load1(lb, eb, r2_ < ROWS1 ? r2_ : LAST1);
+                sum1(la, ea, row);
+                load1(la, ea, r3_ < ROWS1 ? r3_ : LAST1);
+                if (r2_ < ROWS1) sum1(lb, eb, r2_);
+            }
+        }
+        __syncthreads();
+#elif !SINGLE
         {
             T la[W1], ra[W1], lb[W1], rb[W1];
             auto load1 = [&](T (&lv)[W1], T (&rv)[W1], int row) {
@@ -2385,6 +2450,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
             }
         }
         __syncthreads();
+#endif
 #endif
         // ---- list 2: (mid, other operand) -> out; TB terms' operands in flight while the previous TB are summed ----
 #if SPLIT > 1
@@ -2568,6 +2634,7 @@ extern "C" __global__ __launch_bounds__(NT) void gaast_chain(const T* __restrict
     c.cj_sorted[0] = int(wps);
     c.cj_sorted[1] = int(wms);
     c.cj_sorted[2] = int(off_zero * esz);
+    c.cj_xreg = xreg ? 1 : 0;
     c.cj_split = int(split);
     c.cj_ipb = int(ipb);
     c.cj_threads = int(threads);

@@ -122,6 +122,7 @@ struct Step {
     int cj_ipb = 0, cj_threads = 0;
     size_t cj_lds = 0;
     int cj_split = 1;                            // slices per row of list 2 (> 1: re-ordered sums, tolerance mode; 1 with GAAST_FLAG_EXACT_ORDER)
+    int cj_xreg = 0;                             // tolerance mode: list 1's right operand in registers, its table re-ordered by right index (word: left offset | sign << 31)
     int cj_sorted[3] = {0, 0, 0};               // tolerance mode, sign-sorted list 2: plus / minus terms per (row, slice), byte offset of the item's zero element
     int cj_fmt[2] = {0, 0};                     // words per row of list 1's table; list 2's entries: 2 = wide (8 bytes: offsets, then the sign bit), 3 / 4 = sign-sorted clean words (LDS / global), else narrow
     int cj_layout[7] = {0, 0, 0, 0, 0, 0, 0};   // an item in LDS, elements: offsets of l1, r1, the negated image, mid, r2 (-1: aliased); item stride; negated image is of the left operand
